@@ -1,0 +1,267 @@
+/* ptx.h -- C ABI of the MI355X path-tracing hot path (libptx_amd.so).
+ *
+ * The reference (hazard-10/PathTracer, a Scotty3D derivative) has no plugin or FFI
+ * layer: its boundary is the C++ class API PT::Pathtracer / PT::BVH / PT::Tri_Mesh.
+ * This header is the flat boundary those classes' GPU-backed equivalents call; each
+ * entry point cites the reference interface it stands in for (paths relative to the
+ * reference checkout).  Everything is POD: plain pointers and sizes, no C++ types.
+ *
+ * Conventions
+ *  - Every function returning int returns PTX_OK (0) or a negative PtxStatus; the
+ *    message for the calling thread's last failure is ptx_last_error().  Nothing
+ *    throws, aborts or exits across this boundary (the reference's assert/die() do,
+ *    lib/log.h:45-56).
+ *  - The caller owns every buffer it passes and may free it when the call returns.
+ *    The library owns device memory reachable from a handle until *_destroy.
+ *  - Output buffers are caller-allocated.  Pointers are host pointers unless the
+ *    call's `flags` carry PTX_MEM_DEVICE, in which case rays/hits/accumulators are
+ *    device pointers on the scene's device and nothing is copied.
+ *  - Calls are synchronous with respect to the host unless PTX_ASYNC is set, in
+ *    which case work is only enqueued on the scene's stream (device pointers only).
+ *  - A handle may be used by one host thread at a time; use one handle per GPU.
+ *  - Matrices are 16 floats, column-major (element [col*4 + row]), as lib/mat4.h.
+ */
+#ifndef PTX_AMD_H
+#define PTX_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum PtxStatus {
+	PTX_OK = 0,
+	PTX_ERR_INVALID = -1,      /* bad argument (null pointer, index out of range, bad enum) */
+	PTX_ERR_DEVICE = -2,       /* a HIP call failed; message holds hipGetErrorString */
+	PTX_ERR_NO_DEVICE = -3,    /* no GPU visible / device index out of range */
+	PTX_ERR_UNSUPPORTED = -4,  /* valid input the GPU path cannot run (tree too deep, leaf too large) */
+	PTX_ERR_OOM = -5
+} PtxStatus;
+
+/* ------------------------------------------------------------------ flags */
+enum {
+	PTX_MEM_DEVICE = 1u << 0,       /* ray / hit / accumulator pointers are device pointers */
+	PTX_ASYNC = 1u << 1,            /* enqueue only; caller synchronises the stream */
+	/* Traversal semantics (closest-hit):
+	 * REFERENCE visits exactly the nodes PT::BVH::hitRecursive visits (bvh.cpp:272-375): every
+	 *   node whose ancestor chain passes BBox::hit(ray,(0,inf)), left before right, no culling
+	 *   by the running closest distance.  Identical to the reference by construction.
+	 * CULLED visits children near-to-far and skips a subtree whose slab entry is beyond the
+	 *   running closest distance by more than a guard band; ties are still resolved as the
+	 *   reference resolves them (largest position in the BVH-ordered primitive array wins,
+	 *   trace.h:28-36).  Same answers as REFERENCE on well-conditioned input; verified, not
+	 *   proven (a near-parallel ray/triangle pair can compute a distance far from the true one).
+	 */
+	PTX_TRAVERSE_REFERENCE = 0u << 4,
+	PTX_TRAVERSE_CULLED = 1u << 4,
+	PTX_TRAVERSE_MASK = 3u << 4
+};
+
+/* ------------------------------------------------------------------ rays and hits */
+/* lib/ray.h:11-49.  `d` must already be what Ray's constructor would hold (unit length,
+ * ray.h:19): hit() takes a constructed Ray and never renormalises. */
+typedef struct PtxRay {
+	float o[3];
+	float d[3];
+	float tmin, tmax; /* Ray::dist_bounds */
+} PtxRay;             /* 32 bytes */
+
+/* pathtracer/trace.h:10-44 reduced to what identifies a hit.  `distance` is
+ * Trace::distance bit for bit, including the reference's miss values: +inf when no
+ * primitive was tested, 0 when primitives were tested and all missed (Trace::min of two
+ * misses is a default Trace, trace.h:35).  `prim` is the position of the hit primitive in
+ * the BVH-ordered primitive array of its mesh (BVH::primitives after build, bvh.h:53), or
+ * PTX_NO_HIT. */
+#define PTX_NO_HIT 0xFFFFFFFFu
+typedef struct PtxHit {
+	float distance;
+	uint32_t prim;
+} PtxHit; /* 8 bytes */
+
+/* ------------------------------------------------------------------ host BVH (PT::BVH<P>::build, bvh.cpp:31-243) */
+/* One node of the canonical binary tree, the reference's BVH::Node (bvh.h:15-23) with
+ * 32-bit indices.  Leaves have l == r (bvh.h:20). */
+typedef struct PtxBvhNode {
+	float bmin[3], bmax[3];
+	uint32_t start, size, l, r;
+} PtxBvhNode; /* 40 bytes */
+
+typedef struct PtxBvh* ptx_bvh_t;
+
+/* Builds the binned-SAH tree over boxes (n x 6 floats: min xyz, max xyz), 8 bins per axis,
+ * exactly as BVH::build/buildRecursive do, with the bin index clamped to [0,7] and the
+ * partition taken from the bin index (the reference indexes bins[] out of range and lets
+ * ranges and boxes disagree on large inputs).  max_leaf_size: 4 for triangles
+ * (tri_mesh.cpp:173), 1 for instances (bvh.h:26). */
+int ptx_bvh_build(const float* boxes, uint32_t n, uint32_t max_leaf_size, ptx_bvh_t* out);
+/* Convenience: boxes are Triangle::bbox (tri_mesh.cpp:10-44) of an indexed mesh whose
+ * vertices are 8 floats each (position, normal, uv: Tri_Mesh_Vert, tri_mesh.h:13-17). */
+int ptx_bvh_build_triangles(const float* verts, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris,
+                            uint32_t max_leaf_size, ptx_bvh_t* out);
+uint32_t ptx_bvh_num_nodes(ptx_bvh_t bvh);
+uint32_t ptx_bvh_num_prims(ptx_bvh_t bvh);
+uint32_t ptx_bvh_max_depth(ptx_bvh_t bvh);
+int ptx_bvh_get_nodes(ptx_bvh_t bvh, PtxBvhNode* out);      /* num_nodes entries */
+int ptx_bvh_get_order(ptx_bvh_t bvh, uint32_t* out);        /* num_prims entries: input index of the i-th BVH-ordered primitive */
+/* stats[0] primitives whose bin index had to be clamped, [1] primitives the reference's own
+ * partition predicate (bvh.cpp:191-197) would have sent to the other side, [2] primitives
+ * under nodes no split could separate (the reference drops them: bvh.cpp:183-188, 213-221). */
+int ptx_bvh_get_stats(ptx_bvh_t bvh, uint64_t stats[3]);
+void ptx_bvh_destroy(ptx_bvh_t bvh);
+
+/* ------------------------------------------------------------------ scene description (Pathtracer::build_scene, pathtracer.cpp:182-387) */
+typedef struct PtxMeshDesc {                 /* PT::Tri_Mesh(const Indexed_Mesh&, bool), tri_mesh.cpp:160-177 */
+	const float* verts;                      /* n_verts x 8 floats: position, normal, uv */
+	uint32_t n_verts;
+	const uint32_t* indices;                 /* n_tris x 3 */
+	uint32_t n_tris;
+	uint32_t use_bvh;                        /* 0: List<Triangle> (--no_bvh), else BVH<Triangle> */
+	uint32_t max_leaf_size;                  /* 0 means 4 */
+	/* Optional prebuilt tree (BVH::nodes / BVH::primitives are public, bvh.h:53-55): when
+	 * `nodes` is non-null the triangles in `indices` are taken to be in BVH order already
+	 * and no build happens. */
+	const PtxBvhNode* nodes;
+	uint32_t n_nodes;
+} PtxMeshDesc;
+
+enum { PTX_MAT_LAMBERTIAN = 0, PTX_MAT_MIRROR = 1, PTX_MAT_REFRACT = 2, PTX_MAT_GLASS = 3, PTX_MAT_EMISSIVE = 4 };
+enum { PTX_TEX_CONSTANT = 0, PTX_TEX_IMAGE = 1 };
+enum { PTX_SAMPLER_NEAREST = 0, PTX_SAMPLER_BILINEAR = 1 };
+enum { PTX_LIGHT_POINT = 0, PTX_LIGHT_DIRECTIONAL = 1, PTX_LIGHT_SPOT = 2 };
+enum { PTX_ENV_HEMISPHERE = 0, PTX_ENV_SPHERE = 1 };
+/* Materials::schlick (scene/material.cpp:58-71) calls unqualified abs(): with g++ it is
+ * abs(int) and Glass always reflects off-normal; with the float overload it is Schlick. */
+enum { PTX_FRESNEL_GCC_INT_ABS = 0, PTX_FRESNEL_FLOAT_ABS = 1 };
+
+typedef struct PtxTextureDesc {              /* scene/texture.h: Textures::Constant / Textures::Image */
+	uint32_t type;
+	float color[3];
+	float scale;
+	uint32_t sampler, w, h;
+	const float* pixels;                     /* w*h*3 floats, row 0 at the bottom (hdr_image.h:13) */
+} PtxTextureDesc;
+
+typedef struct PtxMaterialDesc {             /* scene/material.h */
+	uint32_t type;
+	int32_t tex_a;                           /* albedo | reflectance | emissive */
+	int32_t tex_b;                           /* transmittance (Refract, Glass) */
+	float ior;
+} PtxMaterialDesc;
+
+typedef struct PtxInstanceDesc {             /* PT::Instance, pathtracer/instance.h:15-40 */
+	int32_t mesh;                            /* index into meshes, or -1 for a Shapes::Sphere of `sphere_radius` */
+	float sphere_radius;
+	int32_t material;                        /* index into materials; -1 = default Lambertian(0) (pathtracer.cpp:240-252) */
+	float T[16];                             /* local_to_world */
+} PtxInstanceDesc;
+
+typedef struct PtxDeltaLightDesc {           /* scene/delta_light.h + PT::Light_Instance */
+	uint32_t type;
+	float color[3];
+	float intensity, inner_angle, outer_angle;
+	float T[16];
+} PtxDeltaLightDesc;
+
+typedef struct PtxEnvLightDesc {             /* scene/env_light.h */
+	uint32_t type;
+	int32_t tex;
+} PtxEnvLightDesc;
+
+typedef struct PtxSceneDesc {
+	const PtxMeshDesc* meshes;
+	uint32_t n_meshes;
+	const PtxInstanceDesc* instances;
+	uint32_t n_instances;
+	const PtxTextureDesc* textures;
+	uint32_t n_textures;
+	const PtxMaterialDesc* materials;
+	uint32_t n_materials;
+	const PtxDeltaLightDesc* delta_lights;
+	uint32_t n_delta_lights;
+	const PtxEnvLightDesc* env_lights;
+	uint32_t n_env_lights;
+	uint32_t use_bvh;                        /* top level: BVH<Instance> or List<Instance> (pathtracer.cpp:381-385) */
+	uint32_t fresnel_mode;                   /* PTX_FRESNEL_* */
+} PtxSceneDesc;
+
+typedef struct PtxScene* ptx_scene_t;
+
+int ptx_device_count(void);
+const char* ptx_last_error(void);
+const char* ptx_version(void);
+
+/* Pathtracer::build_scene (pathtracer.cpp:182-387): builds every mesh BVH and the
+ * instance BVH on the host, flattens them and uploads to `device`. */
+int ptx_scene_create(int device, const PtxSceneDesc* desc, ptx_scene_t* out);
+/* A scene that is one untransformed Tri_Mesh: hit queries on it are PT::Tri_Mesh::hit
+ * (tri_mesh.cpp:193-196) rather than Aggregate::hit. */
+int ptx_scene_create_mesh(int device, const PtxMeshDesc* mesh, ptx_scene_t* out);
+void ptx_scene_destroy(ptx_scene_t scene);
+/* Work is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream). */
+int ptx_scene_set_stream(ptx_scene_t scene, void* hip_stream);
+/* For a mesh scene: the tree the library built (same layout as ptx_bvh_get_*). */
+uint32_t ptx_scene_mesh_num_nodes(ptx_scene_t scene, uint32_t mesh);
+int ptx_scene_mesh_get_nodes(ptx_scene_t scene, uint32_t mesh, PtxBvhNode* out);
+int ptx_scene_mesh_get_order(ptx_scene_t scene, uint32_t mesh, uint32_t* out);
+/* BVH-ordered instance array of the top level: input index of the i-th instance. */
+int ptx_scene_get_instance_order(ptx_scene_t scene, uint32_t* out);
+
+/* ------------------------------------------------------------------ ray queries */
+/* Closest hit: Aggregate::hit -> BVH<Instance>::hit -> Instance::hit -> Tri_Mesh::hit ->
+ * BVH<Triangle>::hit -> Triangle::hit (aggregate.h:41, bvh.cpp:246-375, instance.h:32-40,
+ * tri_mesh.cpp:46-111, 193-196).  hits[i] as documented at PtxHit; bary (nullable) receives
+ * Triangle::hit's (u, v) per ray; inst (nullable) the position of the hit instance in the
+ * BVH-ordered instance array. */
+int ptx_trace_closest(ptx_scene_t scene, const PtxRay* rays, uint64_t n, PtxHit* hits, float* bary, uint32_t* inst,
+                      uint32_t flags);
+/* Occlusion: the reference's only any-hit query is sum_delta_lights' shadow ray,
+ * `scene.hit(shadow_ray).hit` (pathtracer.cpp:657-660).  occluded[i] = that boolean,
+ * computed with early exit on the first accepted triangle. */
+int ptx_trace_any(ptx_scene_t scene, const PtxRay* rays, uint64_t n, uint8_t* occluded, uint32_t flags);
+
+/* ------------------------------------------------------------------ rendering */
+typedef struct PtxCamera {                   /* scene/camera.h:12-30 + Pathtracer::set_camera (pathtracer.cpp:389-396) */
+	float vertical_fov, aspect_ratio;
+	uint32_t film_width, film_height, film_samples, film_max_ray_depth;
+	float camera_to_world[16];
+} PtxCamera;
+
+typedef struct PtxTile {                     /* Pathtracer::Tile, pathtracer.cpp:536-546 */
+	uint32_t seed, x_begin, x_end, y_begin, y_end, s_begin, s_end;
+} PtxTile;
+
+/* Pathtracer::do_trace + accumulate (pathtracer.cpp:444-477, 407-427) for a batch of tiles:
+ * for every pixel of every tile, the tile's samples are traced (Pathtracer::trace,
+ * pathtracer.cpp:126-173) and summed in float in sample order, non-finite samples skipped;
+ * then accum_rgb[3*pixel + c] += int64(sum_c * 2^24) and samples[pixel] += s_end - s_begin.
+ * accum_rgb (3 x int64 per pixel, 40.24 fixed point) and samples (uint32 per pixel) are
+ * film_width*film_height entries and are accumulated into, not cleared
+ * (render(..., add_samples = true), pathtracer.cpp:504-519).
+ * Random numbers: Philox-4x32-10 with key = seed and one stream per (pixel, sample); draw i of
+ * a path is the i-th number the reference's RNG::unit() would have produced on that path.
+ * PtxTile::seed is ignored (it seeds the reference's per-tile mt19937). */
+int ptx_render_tiles(ptx_scene_t scene, const PtxCamera* camera, const PtxTile* tiles, uint32_t n_tiles, uint64_t seed,
+                     int64_t* accum_rgb, uint32_t* samples, uint32_t flags);
+
+/* Pathtracer::render's tile list (pathtracer.cpp:522-563): 100x100-pixel x 50-sample tiles,
+ * seeded from one mt19937(fixed_seed) in y, x, s order, stably sorted centre-out then by
+ * s_begin.  Returns the tile count; writes at most `cap` tiles when `out` is non-null. */
+uint32_t ptx_make_tiles(uint32_t film_width, uint32_t film_height, uint32_t film_samples, uint32_t fixed_seed, PtxTile* out,
+                        uint32_t cap);
+/* Pathtracer::accumulator_to_image (pathtracer.cpp:429-442): rgb[3*i+c] = acc / 2^24 / samples in double. */
+int ptx_accumulator_to_image(const int64_t* accum_rgb, const uint32_t* samples, uint64_t n_pixels, float* rgb);
+/* HDR_Image::tonemap_to (util/hdr_image.cpp:201-225): 1-exp(-c*exposure), sRGB, round(*255); RGBA8. */
+int ptx_tonemap(const float* rgb, uint64_t n_pixels, float exposure, uint8_t* rgba);
+
+typedef struct PtxCounters {
+	uint64_t rays_closest;   /* closest-hit queries since the scene was created */
+	uint64_t rays_any;       /* occlusion queries */
+	uint64_t paths;          /* camera samples traced by ptx_render_tiles */
+} PtxCounters;
+int ptx_get_counters(ptx_scene_t scene, PtxCounters* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTX_AMD_H */

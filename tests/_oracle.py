@@ -1,0 +1,443 @@
+"""ctypes bindings of the CPU checkers (test infrastructure).
+
+`Oracle`  = oracle/liboracle.so, the CPU restatement of the reference hot path (built anywhere).
+`Ref`     = oracle/_ref/libptref.so, the reference's own sources (only where it was built:
+            the development container; the file travels to the GPU box, the sources do not).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pathtracer_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libptref.so")
+
+vp = C.c_void_p
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+u64p = C.POINTER(C.c_uint64)
+i64p = C.POINTER(C.c_int64)
+rayp = C.POINTER(abi.PtxRay)
+hitp = C.POINTER(abi.PtxHit)
+nodep = C.POINTER(abi.PtxBvhNode)
+
+
+def build_oracle():
+    """Compile oracle/liboracle.so if it is missing or stale (g++ only; a few seconds)."""
+    src = [os.path.join(ROOT, "oracle", f) for f in ("ref_cpu_capi.cpp", "ref_cpu.h")] + [os.path.join(ROOT, "include", "ptx.h")]
+    if os.path.exists(ORACLE_SO) and all(os.path.getmtime(ORACLE_SO) >= os.path.getmtime(s) for s in src):
+        return
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "liboracle.so")])
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def as_rays(rays):
+    rays = np.ascontiguousarray(rays)
+    if rays.dtype != abi.RAY_DTYPE:
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8).view(abi.RAY_DTYPE).reshape(-1)
+    return rays
+
+
+def one_ray(o, d, tmin=0.0, tmax=np.inf):
+    r = np.zeros(1, dtype=abi.RAY_DTYPE)
+    r["o"], r["d"], r["tmin"], r["tmax"] = o, d, tmin, tmax
+    return r
+
+
+class Oracle:
+    def __init__(self):
+        build_oracle()
+        L = self.L = C.CDLL(ORACLE_SO)
+        L.orc_scene_create.restype = vp
+        L.orc_scene_create.argtypes = [C.POINTER(abi.PtxSceneDesc)]
+        L.orc_scene_create_mesh.restype = vp
+        L.orc_scene_create_mesh.argtypes = [C.POINTER(abi.PtxMeshDesc)]
+        L.orc_scene_destroy.argtypes = [vp]
+        L.orc_scene_mesh_num_nodes.restype = C.c_uint32
+        L.orc_scene_mesh_num_nodes.argtypes = [vp, C.c_uint32]
+        L.orc_scene_mesh_get_nodes.argtypes = [vp, C.c_uint32, nodep]
+        L.orc_scene_mesh_get_order.argtypes = [vp, C.c_uint32, abi.u32p]
+        L.orc_scene_mesh_get_stats.argtypes = [vp, C.c_uint32, u64p]
+        L.orc_scene_top_num_nodes.restype = C.c_uint32
+        L.orc_scene_top_num_nodes.argtypes = [vp]
+        L.orc_scene_top_get_nodes.argtypes = [vp, nodep]
+        L.orc_scene_get_instance_order.argtypes = [vp, abi.u32p]
+        L.orc_trace_closest.argtypes = [vp, rayp, C.c_uint64, hitp, abi.f32p, abi.u32p, abi.f32p, abi.f32p, abi.f32p, i32p, u64p, C.c_int]
+        L.orc_trace_any.argtypes = [vp, rayp, C.c_uint64, u8p, C.c_int]
+        L.orc_make_tiles.restype = C.c_uint32
+        L.orc_make_tiles.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(abi.PtxTile), C.c_uint32]
+        L.orc_render_tiles.argtypes = [vp, C.POINTER(abi.PtxCamera), C.POINTER(abi.PtxTile), C.c_uint32, C.c_int, C.c_uint64, i64p, abi.u32p, u64p, C.c_int]
+        L.orc_accumulator_to_image.argtypes = [i64p, abi.u32p, C.c_uint64, abi.f32p]
+        L.orc_tonemap.argtypes = [abi.f32p, C.c_uint64, C.c_float, u8p]
+        L.orc_triangle_hit.restype = C.c_int
+        L.orc_triangle_hit.argtypes = [abi.f32p, rayp, abi.f32p]
+        L.orc_triangle_bbox.argtypes = [abi.f32p, abi.f32p]
+        L.orc_bbox_hit.restype = C.c_int
+        L.orc_bbox_hit.argtypes = [abi.f32p, rayp, abi.f32p]
+        L.orc_sphere_hit.restype = C.c_int
+        L.orc_sphere_hit.argtypes = [C.c_float, rayp, abi.f32p]
+        L.orc_material_scatter.argtypes = [C.c_uint32, abi.f32p, abi.f32p, C.c_float, C.c_int, C.c_uint32, abi.f32p, C.c_uint32, abi.f32p]
+        L.orc_mat4_inverse.argtypes = [abi.f32p, abi.f32p]
+        L.orc_rotate_to.argtypes = [abi.f32p, abi.f32p]
+        L.orc_rng_units.argtypes = [C.c_uint32, C.c_uint32, abi.f32p]
+        L.orc_philox_units.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, abi.f32p]
+        L.orc_env_evaluate.argtypes = [vp, C.c_uint32, abi.f32p, abi.f32p]
+        L.orc_camera_ray.argtypes = [C.POINTER(abi.PtxCamera), C.c_uint32, C.c_uint32, C.c_float, C.c_float, rayp]
+
+    # ---- scenes
+    def scene(self, desc):
+        return OracleScene(self, self.L.orc_scene_create(C.byref(desc)))
+
+    def mesh_scene(self, mesh_desc):
+        return OracleScene(self, self.L.orc_scene_create_mesh(C.byref(mesh_desc)))
+
+    def make_tiles(self, w, h, samples, seed):
+        n = self.L.orc_make_tiles(w, h, samples, seed, None, 0)
+        out = np.zeros(n, dtype=abi.TILE_DTYPE)
+        self.L.orc_make_tiles(w, h, samples, seed, out.ctypes.data_as(C.POINTER(abi.PtxTile)), n)
+        return out
+
+    def accumulator_to_image(self, acc, samples):
+        rgb = np.zeros((len(samples), 3), dtype=np.float32)
+        self.L.orc_accumulator_to_image(_ptr(acc, i64p), _ptr(samples, abi.u32p), len(samples), abi.fptr(rgb))
+        return rgb
+
+    def tonemap(self, rgb, exposure):
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((len(rgb), 4), dtype=np.uint8)
+        self.L.orc_tonemap(abi.fptr(rgb), len(rgb), exposure, _ptr(out, u8p))
+        return out
+
+    # ---- probes
+    def triangle_hit(self, verts24, ray):
+        verts24 = np.ascontiguousarray(verts24, dtype=np.float32).reshape(24)
+        out = np.zeros(12, dtype=np.float32)
+        h = self.L.orc_triangle_hit(abi.fptr(verts24), _ptr(as_rays(ray), rayp), abi.fptr(out))
+        return bool(h), out
+
+    def triangle_bbox(self, verts24):
+        verts24 = np.ascontiguousarray(verts24, dtype=np.float32).reshape(24)
+        out = np.zeros(6, dtype=np.float32)
+        self.L.orc_triangle_bbox(abi.fptr(verts24), abi.fptr(out))
+        return out
+
+    def bbox_hit(self, box6, ray, times=(0.0, np.inf)):
+        box6 = np.ascontiguousarray(box6, dtype=np.float32).reshape(6)
+        t = np.array(times, dtype=np.float32)
+        h = self.L.orc_bbox_hit(abi.fptr(box6), _ptr(as_rays(ray), rayp), abi.fptr(t))
+        return bool(h), t
+
+    def sphere_hit(self, radius, ray):
+        out = np.zeros(9, dtype=np.float32)
+        h = self.L.orc_sphere_hit(radius, _ptr(as_rays(ray), rayp), abi.fptr(out))
+        return bool(h), out
+
+    def material_scatter(self, mtype, color_a, color_b, ior, fresnel_mode, seed, out_dirs):
+        out_dirs = np.ascontiguousarray(out_dirs, dtype=np.float32).reshape(-1, 3)
+        ca, cb = np.array(color_a, dtype=np.float32), np.array(color_b, dtype=np.float32)
+        out = np.zeros((len(out_dirs), 7), dtype=np.float32)
+        self.L.orc_material_scatter(mtype, abi.fptr(ca), abi.fptr(cb), ior, fresnel_mode, seed, abi.fptr(out_dirs), len(out_dirs), abi.fptr(out))
+        return out
+
+    def mat4_inverse(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float32).reshape(16)
+        out = np.zeros(16, dtype=np.float32)
+        self.L.orc_mat4_inverse(abi.fptr(m), abi.fptr(out))
+        return out
+
+    def rotate_to(self, d):
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(3)
+        out = np.zeros(16, dtype=np.float32)
+        self.L.orc_rotate_to(abi.fptr(d), abi.fptr(out))
+        return out
+
+    def rng_units(self, seed, n):
+        out = np.zeros(n, dtype=np.float32)
+        self.L.orc_rng_units(seed, n, abi.fptr(out))
+        return out
+
+    def philox_units(self, seed, pixel, sample, n):
+        out = np.zeros(n, dtype=np.float32)
+        self.L.orc_philox_units(seed, pixel, sample, n, abi.fptr(out))
+        return out
+
+    def camera_ray(self, cam, px, py, a, b):
+        r = np.zeros(1, dtype=abi.RAY_DTYPE)
+        self.L.orc_camera_ray(C.byref(cam), px, py, a, b, _ptr(r, rayp))
+        return r
+
+
+class OracleScene:
+    def __init__(self, o, h):
+        self.o, self.h = o, h
+
+    def close(self):
+        if self.h:
+            self.o.L.orc_scene_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def mesh_nodes(self, mesh=0):
+        n = self.o.L.orc_scene_mesh_num_nodes(self.h, mesh)
+        out = np.zeros(n, dtype=abi.NODE_DTYPE)
+        self.o.L.orc_scene_mesh_get_nodes(self.h, mesh, _ptr(out, nodep))
+        return out
+
+    def mesh_order(self, n_tris, mesh=0):
+        out = np.zeros(n_tris, dtype=np.uint32)
+        self.o.L.orc_scene_mesh_get_order(self.h, mesh, abi.uptr(out))
+        return out
+
+    def mesh_stats(self, mesh=0):
+        out = np.zeros(3, dtype=np.uint64)
+        self.o.L.orc_scene_mesh_get_stats(self.h, mesh, _ptr(out, u64p))
+        return out
+
+    def top_nodes(self):
+        n = self.o.L.orc_scene_top_num_nodes(self.h)
+        out = np.zeros(n, dtype=abi.NODE_DTYPE)
+        self.o.L.orc_scene_top_get_nodes(self.h, _ptr(out, nodep))
+        return out
+
+    def instance_order(self, n):
+        out = np.zeros(n, dtype=np.uint32)
+        self.o.L.orc_scene_get_instance_order(self.h, abi.uptr(out))
+        return out
+
+    def trace_closest(self, rays, nthreads=8, full=False, counters=False):
+        rays = as_rays(rays)
+        n = len(rays)
+        hits = np.zeros(n, dtype=abi.HIT_DTYPE)
+        bary = np.zeros((n, 2), dtype=np.float32)
+        inst = np.zeros(n, dtype=np.uint32)
+        pos = np.zeros((n, 3), dtype=np.float32) if full else None
+        nrm = np.zeros((n, 3), dtype=np.float32) if full else None
+        uv = np.zeros((n, 2), dtype=np.float32) if full else None
+        mat = np.zeros(n, dtype=np.int32) if full else None
+        ctr = np.zeros(2, dtype=np.uint64) if counters else None
+        self.o.L.orc_trace_closest(self.h, _ptr(rays, rayp), n, _ptr(hits, hitp), abi.fptr(bary), abi.uptr(inst), _ptr(pos, abi.f32p),
+                                   _ptr(nrm, abi.f32p), _ptr(uv, abi.f32p), _ptr(mat, i32p), _ptr(ctr, u64p), nthreads)
+        res = dict(hits=hits, bary=bary, inst=inst)
+        if full:
+            res.update(pos=pos, normal=nrm, uv=uv, material=mat)
+        if counters:
+            res["counters"] = ctr
+        return res
+
+    def trace_any(self, rays, nthreads=8):
+        rays = as_rays(rays)
+        out = np.zeros(len(rays), dtype=np.uint8)
+        self.o.L.orc_trace_any(self.h, _ptr(rays, rayp), len(rays), _ptr(out, u8p), nthreads)
+        return out
+
+    def render_tiles(self, cam, tiles, rng_mode, seed, nthreads=8, stats=False):
+        npix = cam.film_width * cam.film_height
+        acc = np.zeros(npix * 3, dtype=np.int64)
+        smp = np.zeros(npix, dtype=np.uint32)
+        st = np.zeros(2, dtype=np.uint64) if stats else None
+        tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
+        self.o.L.orc_render_tiles(self.h, C.byref(cam), tiles.ctypes.data_as(C.POINTER(abi.PtxTile)), len(tiles), rng_mode, seed,
+                                  _ptr(acc, i64p), abi.uptr(smp), _ptr(st, u64p), nthreads)
+        return (acc, smp, st) if stats else (acc, smp)
+
+    def env_evaluate(self, light, d):
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(3)
+        out = np.zeros(3, dtype=np.float32)
+        self.o.L.orc_env_evaluate(self.h, light, abi.fptr(d), abi.fptr(out))
+        return out
+
+
+class Ref:
+    """The reference's own code (oracle/_ref/libptref.so).  `Ref.available()` says whether it was built."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SO)
+
+    def __init__(self):
+        L = self.L = C.CDLL(REF_SO)
+        L.ref_mesh_create.restype = vp
+        L.ref_mesh_create.argtypes = [abi.f32p, C.c_uint32, abi.u32p, C.c_uint32, C.c_int, C.c_uint32, C.c_int, nodep, C.c_uint32]
+        L.ref_mesh_destroy.argtypes = [vp]
+        L.ref_mesh_num_nodes.restype = C.c_uint32
+        L.ref_mesh_num_nodes.argtypes = [vp]
+        L.ref_mesh_get_nodes.argtypes = [vp, nodep]
+        L.ref_mesh_get_prim_boxes.argtypes = [vp, abi.f32p]
+        L.ref_mesh_hit.argtypes = [vp, rayp, C.c_uint64, hitp, abi.f32p, abi.f32p, abi.f32p, C.c_int]
+        L.ref_scene_create.restype = vp
+        L.ref_scene_create.argtypes = [C.POINTER(abi.PtxSceneDesc)]
+        L.ref_scene_destroy.argtypes = [vp]
+        L.ref_scene_hit.argtypes = [vp, rayp, C.c_uint64, u8p, abi.f32p, abi.f32p, abi.f32p, abi.f32p, i32p, C.c_int]
+        L.ref_triangle_hit.restype = C.c_int
+        L.ref_triangle_hit.argtypes = [abi.f32p, rayp, abi.f32p]
+        L.ref_triangle_bbox.argtypes = [abi.f32p, abi.f32p]
+        L.ref_bbox_hit.restype = C.c_int
+        L.ref_bbox_hit.argtypes = [abi.f32p, rayp, abi.f32p]
+        L.ref_sphere_hit.restype = C.c_int
+        L.ref_sphere_hit.argtypes = [C.c_float, rayp, abi.f32p]
+        L.ref_material_scatter.argtypes = [C.c_uint32, abi.f32p, abi.f32p, C.c_float, C.c_uint32, abi.f32p, C.c_uint32, abi.f32p]
+        L.ref_mat4_inverse.argtypes = [abi.f32p, abi.f32p]
+        L.ref_rotate_to.argtypes = [abi.f32p, abi.f32p]
+        L.ref_rng_units.argtypes = [C.c_uint32, C.c_uint32, abi.f32p]
+        L.ref_env_sphere_evaluate.argtypes = [C.c_uint32, C.c_uint32, abi.f32p, C.c_int, abi.f32p, C.c_uint32, abi.f32p]
+        L.ref_sphere_mesh.argtypes = [C.c_float, C.c_uint32, abi.u32p, abi.u32p, abi.f32p, abi.u32p]
+        L.ref_fuzz_mesh.restype = C.c_uint32
+        L.ref_fuzz_mesh.argtypes = [C.c_uint32, abi.f32p, C.c_uint32, rayp, C.c_uint32]
+        L.ref_ray_make.argtypes = [abi.f32p, abi.f32p, abi.f32p, rayp]
+
+    def mesh(self, verts, indices, use_bvh=True, max_leaf=4, id_coded=True, nodes=None):
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 8)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        nn = 0
+        if nodes is not None:
+            nodes = np.ascontiguousarray(nodes, dtype=abi.NODE_DTYPE)
+            nn = len(nodes)
+        h = self.L.ref_mesh_create(abi.fptr(verts), len(verts), abi.uptr(indices), len(indices), int(use_bvh), max_leaf, int(id_coded),
+                                   _ptr(nodes, nodep), nn)
+        return RefMesh(self, h, len(indices))
+
+    def scene(self, desc):
+        return RefScene(self, self.L.ref_scene_create(C.byref(desc)))
+
+    def sphere_mesh(self, r, subdiv):
+        nv, nt = C.c_uint32(), C.c_uint32()
+        self.L.ref_sphere_mesh(r, subdiv, C.byref(nv), C.byref(nt), None, None)
+        verts = np.zeros((nv.value, 8), dtype=np.float32)
+        idx = np.zeros((nt.value, 3), dtype=np.uint32)
+        self.L.ref_sphere_mesh(r, subdiv, C.byref(nv), C.byref(nt), abi.fptr(verts), abi.uptr(idx))
+        return verts, idx
+
+    def fuzz_mesh(self, seed, n_rays):
+        n = self.L.ref_fuzz_mesh(seed, None, 0, None, 0)
+        verts = np.zeros((n * 3, 8), dtype=np.float32)
+        rays = np.zeros(n_rays, dtype=abi.RAY_DTYPE)
+        self.L.ref_fuzz_mesh(seed, abi.fptr(verts), n, _ptr(rays, rayp), n_rays)
+        idx = np.arange(n * 3, dtype=np.uint32).reshape(-1, 3)
+        return verts, idx, rays
+
+    def ray_make(self, o, d, T=None):
+        o, d = np.array(o, dtype=np.float32), np.array(d, dtype=np.float32)
+        T = None if T is None else np.ascontiguousarray(T, dtype=np.float32).reshape(16)
+        r = np.zeros(1, dtype=abi.RAY_DTYPE)
+        self.L.ref_ray_make(abi.fptr(o), abi.fptr(d), _ptr(T, abi.f32p), _ptr(r, rayp))
+        return r
+
+    def triangle_hit(self, verts24, ray):
+        verts24 = np.ascontiguousarray(verts24, dtype=np.float32).reshape(24)
+        out = np.zeros(12, dtype=np.float32)
+        h = self.L.ref_triangle_hit(abi.fptr(verts24), _ptr(as_rays(ray), rayp), abi.fptr(out))
+        return bool(h), out
+
+    def triangle_bbox(self, verts24):
+        verts24 = np.ascontiguousarray(verts24, dtype=np.float32).reshape(24)
+        out = np.zeros(6, dtype=np.float32)
+        self.L.ref_triangle_bbox(abi.fptr(verts24), abi.fptr(out))
+        return out
+
+    def bbox_hit(self, box6, ray, times=(0.0, np.inf)):
+        box6 = np.ascontiguousarray(box6, dtype=np.float32).reshape(6)
+        t = np.array(times, dtype=np.float32)
+        h = self.L.ref_bbox_hit(abi.fptr(box6), _ptr(as_rays(ray), rayp), abi.fptr(t))
+        return bool(h), t
+
+    def sphere_hit(self, radius, ray):
+        out = np.zeros(9, dtype=np.float32)
+        h = self.L.ref_sphere_hit(radius, _ptr(as_rays(ray), rayp), abi.fptr(out))
+        return bool(h), out
+
+    def material_scatter(self, mtype, color_a, color_b, ior, seed, out_dirs):
+        out_dirs = np.ascontiguousarray(out_dirs, dtype=np.float32).reshape(-1, 3)
+        ca, cb = np.array(color_a, dtype=np.float32), np.array(color_b, dtype=np.float32)
+        out = np.zeros((len(out_dirs), 7), dtype=np.float32)
+        self.L.ref_material_scatter(mtype, abi.fptr(ca), abi.fptr(cb), ior, seed, abi.fptr(out_dirs), len(out_dirs), abi.fptr(out))
+        return out
+
+    def mat4_inverse(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float32).reshape(16)
+        out = np.zeros(16, dtype=np.float32)
+        self.L.ref_mat4_inverse(abi.fptr(m), abi.fptr(out))
+        return out
+
+    def rotate_to(self, d):
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(3)
+        out = np.zeros(16, dtype=np.float32)
+        self.L.ref_rotate_to(abi.fptr(d), abi.fptr(out))
+        return out
+
+    def rng_units(self, seed, n):
+        out = np.zeros(n, dtype=np.float32)
+        self.L.ref_rng_units(seed, n, abi.fptr(out))
+        return out
+
+    def env_sphere_evaluate(self, pixels, sampler, dirs):
+        pixels = np.ascontiguousarray(pixels, dtype=np.float32)
+        h, w, _ = pixels.shape
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((len(dirs), 3), dtype=np.float32)
+        self.L.ref_env_sphere_evaluate(w, h, abi.fptr(pixels), sampler, abi.fptr(dirs), len(dirs), abi.fptr(out))
+        return out
+
+
+class RefMesh:
+    def __init__(self, r, h, n_tris):
+        self.r, self.h, self.n_tris = r, h, n_tris
+
+    def close(self):
+        if self.h:
+            self.r.L.ref_mesh_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def nodes(self):
+        n = self.r.L.ref_mesh_num_nodes(self.h)
+        out = np.zeros(n, dtype=abi.NODE_DTYPE)
+        self.r.L.ref_mesh_get_nodes(self.h, _ptr(out, nodep))
+        return out
+
+    def prim_boxes(self):
+        out = np.zeros((self.n_tris, 6), dtype=np.float32)
+        self.r.L.ref_mesh_get_prim_boxes(self.h, abi.fptr(out))
+        return out
+
+    def hit(self, rays, nthreads=8, full=False):
+        rays = as_rays(rays)
+        n = len(rays)
+        hits = np.zeros(n, dtype=abi.HIT_DTYPE)
+        pos = np.zeros((n, 3), dtype=np.float32) if full else None
+        nrm = np.zeros((n, 3), dtype=np.float32) if full else None
+        uv = np.zeros((n, 2), dtype=np.float32) if full else None
+        self.r.L.ref_mesh_hit(self.h, _ptr(rays, rayp), n, _ptr(hits, hitp), _ptr(pos, abi.f32p), _ptr(nrm, abi.f32p), _ptr(uv, abi.f32p), nthreads)
+        return dict(hits=hits, pos=pos, normal=nrm, uv=uv) if full else dict(hits=hits)
+
+
+class RefScene:
+    def __init__(self, r, h):
+        self.r, self.h = r, h
+
+    def close(self):
+        if self.h:
+            self.r.L.ref_scene_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def hit(self, rays, nthreads=8):
+        rays = as_rays(rays)
+        n = len(rays)
+        hit = np.zeros(n, dtype=np.uint8)
+        dist = np.zeros(n, dtype=np.float32)
+        pos = np.zeros((n, 3), dtype=np.float32)
+        nrm = np.zeros((n, 3), dtype=np.float32)
+        uv = np.zeros((n, 2), dtype=np.float32)
+        mat = np.zeros(n, dtype=np.int32)
+        self.r.L.ref_scene_hit(self.h, _ptr(rays, rayp), n, _ptr(hit, u8p), abi.fptr(dist), abi.fptr(pos), abi.fptr(nrm), abi.fptr(uv), _ptr(mat, i32p), nthreads)
+        return dict(hit=hit, distance=dist, pos=pos, normal=nrm, uv=uv, material=mat)

@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the ray-query hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the one the north star's >= 1 Gray/s target is quoted on):
+16,777,216 incoherent rays against a 1,000,000-triangle procedural soup whose BVH is built
+by the host builder (max_leaf_size 4).  One "step" is one closest-hit pass over the whole ray
+batch, inputs and outputs resident in HBM.  With --gpus N every rank traces its own batch of
+the same size against its own replica of the scene (weak scaling, no data-path collective).
+
+Prints ONE JSON line on rank 0.  `value` is the whole-job closest-hit rate in Mrays/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+
+
+def cpu_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def cpu_baseline_and_counts(verts, idx, nodes, order, rays, target_seconds=12.0):
+    """Times the CPU checker on a bounded prefix of the same ray batch and counts the nodes and
+    triangles a reference-semantics traversal touches (for the algorithmic-bytes figure)."""
+    from _oracle import Oracle, Ref
+    from pathtracer_amd import abi
+    threads = cpu_threads()
+    out = {}
+    oracle = Oracle()
+    sb = abi.SceneBuilder()
+    scene = oracle.mesh_scene(sb.mesh_desc(verts, idx[order], nodes=nodes))
+    # visit counts: reference semantics, 16k-ray prefix
+    probe = rays[:16384]
+    res = scene.trace_closest(probe, nthreads=threads, counters=True)
+    nodes_per_ray = float(res["counters"][0]) / len(probe)
+    tris_per_ray = float(res["counters"][1]) / len(probe)
+    kind = "port"
+    run = lambda r: scene.trace_closest(r, nthreads=threads)
+    if Ref.available():
+        ref = Ref()
+        rmesh = ref.mesh(verts, idx[order], id_coded=True, nodes=nodes)   # the builder's tree injected into the reference BVH
+        run = lambda r: rmesh.hit(r, nthreads=threads)
+        kind = "reference"
+    t0 = time.perf_counter()
+    run(rays[:32768])
+    dt = time.perf_counter() - t0
+    n = int(min(len(rays), max(32768, 32768 * target_seconds / max(dt, 1e-3))))
+    n = (n // 4096) * 4096
+    t0 = time.perf_counter()
+    run(rays[:n])
+    dt = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": round(n / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": kind,
+                           "sample": f"first {n} rays of the same 16M-ray batch, closest-hit, BVH<Triangle>::hit on the same 1M-triangle tree"}
+    out["nodes_per_ray"] = nodes_per_ray
+    out["tris_per_ray"] = tris_per_ray
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rays", type=int, default=1 << 24)
+    ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    from pathtracer_amd import abi, capi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- workload: same scene on every rank, a different ray batch per rank
+    verts, idx = synth.soup(args.tris)
+    t0 = time.perf_counter()
+    bvh = capi.Bvh(verts=verts, indices=idx, max_leaf_size=4)
+    build_s = time.perf_counter() - t0
+    nodes, order = bvh.nodes(), bvh.order()
+    scene = capi.Scene.from_mesh(verts, idx[order], nodes=nodes, device=local_rank)
+    scene.set_stream(torch.cuda.current_stream().cuda_stream)
+    rays_h = synth.rays(args.rays, key=synth.RAY_KEY + 7919 * rank)
+    shadow_h = synth.shadow_rays(args.rays, key=synth.SHADOW_KEY + 7919 * rank)
+    rays = torch.from_numpy(rays_h.view(np.float32).reshape(-1, 8)).to(dev)
+    shadow = torch.from_numpy(shadow_h.view(np.float32).reshape(-1, 8)).to(dev)
+    hits_ref = torch.empty((args.rays, 2), dtype=torch.int32, device=dev)
+    hits = torch.empty((args.rays, 2), dtype=torch.int32, device=dev)
+    occ_ref = torch.empty(args.rays, dtype=torch.uint8, device=dev)
+    occ = torch.empty(args.rays, dtype=torch.uint8, device=dev)
+    n = args.rays
+
+    def closest(mode, out):
+        scene.trace_closest_device(rays, out, flags=mode | abi.PTX_ASYNC, n=n)
+
+    def anyhit(mode, out):
+        scene.trace_any_device(shadow, out, flags=mode | abi.PTX_ASYNC, n=n)
+
+    # ---- correctness of the fast modes on the whole batch, outside the timed region
+    closest(abi.PTX_TRAVERSE_REFERENCE, hits_ref)
+    closest(abi.PTX_TRAVERSE_CULLED, hits)
+    anyhit(abi.PTX_TRAVERSE_REFERENCE, occ_ref)
+    anyhit(abi.PTX_TRAVERSE_CULLED, occ)
+    torch.cuda.synchronize()
+    mismatch_closest = int((hits != hits_ref).any(dim=1).sum().item())
+    mismatch_any = int((occ != occ_ref).sum().item())
+    hit_fraction = float((hits_ref[:, 1] != -1).float().mean().item())
+    headline_mode = abi.PTX_TRAVERSE_CULLED if mismatch_closest == 0 else abi.PTX_TRAVERSE_REFERENCE
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+            w = torch.tensor([wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            wall = float(w.item())
+        return wall, e0.elapsed_time(e1) / steps   # whole-job wall seconds, per-launch device ms (HIP events)
+
+    wall, kernel_ms = timed(lambda: closest(headline_mode, hits), args.steps, args.warmup)
+    ms_per_step = wall * 1e3 / args.steps
+    value = n * world * args.steps / wall / 1e6
+
+    # secondary figures (not part of `value`)
+    _, ref_ms = timed(lambda: closest(abi.PTX_TRAVERSE_REFERENCE, hits_ref), max(1, args.steps // 3), 1)
+    _, any_ms = timed(lambda: anyhit(abi.PTX_TRAVERSE_CULLED if mismatch_any == 0 else abi.PTX_TRAVERSE_REFERENCE, occ), args.steps, 1)
+
+    result = {
+        "metric": "Mrays/sec closest-hit", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"config 3: {n} incoherent rays per GPU vs {args.tris}-triangle soup BVH (max_leaf 4), closest-hit (t, primitive id)",
+                   "traversal": "culled" if headline_mode == abi.PTX_TRAVERSE_CULLED else "reference", "rays_per_gpu": n,
+                   "triangles": args.tris, "bvh_nodes": int(len(nodes)), "bvh_build_s": round(build_s, 3)},
+        "parity": {"culled_vs_reference_mode_mismatches": mismatch_closest, "anyhit_culled_vs_reference_mismatches": mismatch_any,
+                   "rays_checked": n, "hit_fraction": round(hit_fraction, 4)},
+        "reference_mode_mrays_per_s": round(n / ref_ms / 1e3, 2),
+        "anyhit_mrays_per_s": round(n / any_ms / 1e3, 2),
+    }
+
+    if rank == 0:
+        extra = {}
+        if world == 1 and not args.no_cpu:
+            extra = cpu_baseline_and_counts(verts, idx, nodes, order, rays_h)
+            result["cpu_baseline"] = extra["cpu_baseline"]
+        if extra:
+            # algorithmic bytes per ray: ray in + hit out + 32 B per node box tested + 36 B per triangle
+            # tested by a reference-semantics traversal of the canonical binary tree
+            b_ray = 32 + 8 + 32 * extra["nodes_per_ray"] + 36 * extra["tris_per_ray"]
+            achieved = b_ray * n / (kernel_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("closest_culled_hbm_bytes_per_launch")
+            result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                  "kernel_ms": round(kernel_ms, 4), "bytes_per_ray": round(b_ray, 1),
+                                  "nodes_per_ray": round(extra["nodes_per_ray"], 2), "tris_per_ray": round(extra["tris_per_ray"], 2),
+                                  "note": "algorithmic bytes of a reference-semantics traversal; the working set (nodes + triangles) fits the 256 MiB Infinity Cache"}
+        print(json.dumps(result), flush=True)
+    scene.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -641,6 +641,7 @@ struct Instance {
 		if (trace.hit) {
 			trace.material = material;
 			trace.inst = array_index;
+			if (!mesh) trace.prim = 0;   // a sphere has one primitive
 			if (has_transform) trace.transform(T, iT.T());
 		}
 		return trace;

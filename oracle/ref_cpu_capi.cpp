@@ -25,7 +25,12 @@ M4 mat_from(const float* t) {
 struct OScene {
 	Scene scene;
 	bool mesh_only = false;  // queries are Tri_Mesh::hit on meshes[0]
-	Trace hit(const Ray& r, Counters* c) const { return mesh_only ? scene.meshes[0]->hit(r, c) : scene.hit(r, c); }
+	Trace hit(const Ray& r, Counters* c) const {
+		if (!mesh_only) return scene.hit(r, c);
+		Trace t = scene.meshes[0]->hit(r, c);
+		if (t.hit) t.inst = 0;
+		return t;
+	}
 };
 
 TriMesh* make_mesh(const PtxMeshDesc& d) {

@@ -1,0 +1,232 @@
+"""Loader and thin Python mirror of the C ABI in include/ptx.h (libptx_amd.so).
+
+There is no CPU fallback: if the library is missing, or a call fails, this module raises.
+Arrays are numpy (host pointers) or torch CUDA tensors (device pointers, PTX_MEM_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libptx_amd.so")
+
+vp = C.c_void_p
+_lib = None
+
+
+class PtxError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded C ABI library.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PtxError(f"{LIB_PATH} is missing: build it with `make -C pathtracer_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.ptx_last_error.restype = C.c_char_p
+    L.ptx_version.restype = C.c_char_p
+    L.ptx_device_count.restype = C.c_int
+    L.ptx_bvh_build.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.ptx_bvh_build_triangles.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    for f in ("ptx_bvh_num_nodes", "ptx_bvh_num_prims", "ptx_bvh_max_depth"):
+        getattr(L, f).restype = C.c_uint32
+        getattr(L, f).argtypes = [vp]
+    L.ptx_bvh_get_nodes.argtypes = [vp, vp]
+    L.ptx_bvh_get_order.argtypes = [vp, vp]
+    L.ptx_bvh_get_stats.argtypes = [vp, vp]
+    L.ptx_bvh_destroy.argtypes = [vp]
+    L.ptx_bvh_destroy.restype = None
+    L.ptx_scene_create.argtypes = [C.c_int, C.POINTER(abi.PtxSceneDesc), C.POINTER(vp)]
+    L.ptx_scene_create_mesh.argtypes = [C.c_int, C.POINTER(abi.PtxMeshDesc), C.POINTER(vp)]
+    L.ptx_scene_destroy.argtypes = [vp]
+    L.ptx_scene_destroy.restype = None
+    L.ptx_scene_set_stream.argtypes = [vp, vp]
+    L.ptx_scene_mesh_num_nodes.restype = C.c_uint32
+    L.ptx_scene_mesh_num_nodes.argtypes = [vp, C.c_uint32]
+    L.ptx_scene_mesh_get_nodes.argtypes = [vp, C.c_uint32, vp]
+    L.ptx_scene_mesh_get_order.argtypes = [vp, C.c_uint32, vp]
+    L.ptx_scene_get_instance_order.argtypes = [vp, vp]
+    L.ptx_trace_closest.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint32]
+    L.ptx_trace_any.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32]
+    L.ptx_render_tiles.argtypes = [vp, C.POINTER(abi.PtxCamera), vp, C.c_uint32, C.c_uint64, vp, vp, C.c_uint32]
+    L.ptx_make_tiles.restype = C.c_uint32
+    L.ptx_make_tiles.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32]
+    L.ptx_accumulator_to_image.argtypes = [vp, vp, C.c_uint64, vp]
+    L.ptx_tonemap.argtypes = [vp, C.c_uint64, C.c_float, vp]
+    L.ptx_get_counters.argtypes = [vp, C.POINTER(abi.PtxCounters)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != abi.PTX_OK:
+        raise PtxError(f"ptx error {rc}: {lib().ptx_last_error().decode()}")
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _addr(x):
+    """(address, is_device) of a numpy array or a torch tensor; None -> (None, None)."""
+    if x is None:
+        return None, None
+    if _is_torch(x):
+        assert x.is_contiguous()
+        return x.data_ptr(), x.is_cuda
+    assert x.flags["C_CONTIGUOUS"]
+    return x.ctypes.data, False
+
+
+class Bvh:
+    """Host tree: PT::BVH<P>::build (bvh.cpp:31-243) over boxes or over an indexed triangle mesh."""
+
+    def __init__(self, boxes=None, verts=None, indices=None, max_leaf_size=4):
+        self.h = vp()
+        if boxes is not None:
+            boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+            check(lib().ptx_bvh_build(boxes.ctypes.data, len(boxes), max_leaf_size, C.byref(self.h)))
+        else:
+            verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 8)
+            indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+            check(lib().ptx_bvh_build_triangles(verts.ctypes.data, len(verts), indices.ctypes.data, len(indices), max_leaf_size, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().ptx_bvh_destroy(self.h)
+            self.h = vp()
+
+    __del__ = close
+
+    @property
+    def max_depth(self):
+        return lib().ptx_bvh_max_depth(self.h)
+
+    def nodes(self):
+        out = np.zeros(lib().ptx_bvh_num_nodes(self.h), dtype=abi.NODE_DTYPE)
+        check(lib().ptx_bvh_get_nodes(self.h, out.ctypes.data))
+        return out
+
+    def order(self):
+        out = np.zeros(lib().ptx_bvh_num_prims(self.h), dtype=np.uint32)
+        check(lib().ptx_bvh_get_order(self.h, out.ctypes.data))
+        return out
+
+    def stats(self):
+        out = np.zeros(3, dtype=np.uint64)
+        check(lib().ptx_bvh_get_stats(self.h, out.ctypes.data))
+        return out
+
+
+class Scene:
+    """A scene resident on one GPU (ptx_scene_t)."""
+
+    def __init__(self, desc=None, mesh_desc=None, device=0, keep=None):
+        self.h = vp()
+        self._keep = keep
+        if mesh_desc is not None:
+            check(lib().ptx_scene_create_mesh(device, C.byref(mesh_desc), C.byref(self.h)))
+        else:
+            check(lib().ptx_scene_create(device, C.byref(desc), C.byref(self.h)))
+
+    @classmethod
+    def from_mesh(cls, verts, indices, use_bvh=True, max_leaf_size=0, nodes=None, device=0):
+        sb = abi.SceneBuilder()
+        return cls(mesh_desc=sb.mesh_desc(verts, indices, use_bvh, max_leaf_size, nodes), device=device, keep=sb)
+
+    def close(self):
+        if self.h:
+            lib().ptx_scene_destroy(self.h)
+            self.h = vp()
+
+    __del__ = close
+
+    def set_stream(self, stream_handle):
+        check(lib().ptx_scene_set_stream(self.h, stream_handle))
+
+    def mesh_nodes(self, mesh=0):
+        out = np.zeros(lib().ptx_scene_mesh_num_nodes(self.h, mesh), dtype=abi.NODE_DTYPE)
+        check(lib().ptx_scene_mesh_get_nodes(self.h, mesh, out.ctypes.data))
+        return out
+
+    def mesh_order(self, n_tris, mesh=0):
+        out = np.zeros(n_tris, dtype=np.uint32)
+        check(lib().ptx_scene_mesh_get_order(self.h, mesh, out.ctypes.data))
+        return out
+
+    def instance_order(self, n):
+        out = np.zeros(n, dtype=np.uint32)
+        check(lib().ptx_scene_get_instance_order(self.h, out.ctypes.data))
+        return out
+
+    def trace_closest(self, rays, flags=0, want_bary=True, want_inst=True):
+        """Host arrays in, host arrays out: dict(hits, bary, inst)."""
+        rays = np.ascontiguousarray(rays)
+        assert rays.dtype == abi.RAY_DTYPE
+        n = len(rays)
+        hits = np.zeros(n, dtype=abi.HIT_DTYPE)
+        bary = np.zeros((n, 2), dtype=np.float32) if want_bary else None
+        inst = np.zeros(n, dtype=np.uint32) if want_inst else None
+        check(lib().ptx_trace_closest(self.h, rays.ctypes.data, n, hits.ctypes.data, _addr(bary)[0], _addr(inst)[0], flags))
+        return dict(hits=hits, bary=bary, inst=inst)
+
+    def trace_closest_device(self, rays, hits, bary=None, inst=None, flags=0, n=None):
+        """Torch CUDA tensors in and out (nothing is copied): rays uint8/float32 view of PtxRay[n], hits of PtxHit[n]."""
+        n = n if n is not None else rays.numel() * rays.element_size() // 32
+        check(lib().ptx_trace_closest(self.h, rays.data_ptr(), n, hits.data_ptr(), _addr(bary)[0], _addr(inst)[0], flags | abi.PTX_MEM_DEVICE))
+
+    def trace_any(self, rays, flags=0):
+        rays = np.ascontiguousarray(rays)
+        assert rays.dtype == abi.RAY_DTYPE
+        out = np.zeros(len(rays), dtype=np.uint8)
+        check(lib().ptx_trace_any(self.h, rays.ctypes.data, len(rays), out.ctypes.data, flags))
+        return out
+
+    def trace_any_device(self, rays, occluded, flags=0, n=None):
+        n = n if n is not None else rays.numel() * rays.element_size() // 32
+        check(lib().ptx_trace_any(self.h, rays.data_ptr(), n, occluded.data_ptr(), flags | abi.PTX_MEM_DEVICE))
+
+    def render_tiles(self, cam, tiles, seed, accum=None, samples=None, flags=0):
+        npix = cam.film_width * cam.film_height
+        tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
+        if accum is None:
+            accum = np.zeros(npix * 3, dtype=np.int64)
+            samples = np.zeros(npix, dtype=np.uint32)
+        a, dev = _addr(accum)
+        if dev:
+            flags |= abi.PTX_MEM_DEVICE
+        check(lib().ptx_render_tiles(self.h, C.byref(cam), tiles.ctypes.data, len(tiles), seed, a, _addr(samples)[0], flags))
+        return accum, samples
+
+    def counters(self):
+        c = abi.PtxCounters()
+        check(lib().ptx_get_counters(self.h, C.byref(c)))
+        return c
+
+
+def make_tiles(w, h, samples, fixed_seed):
+    n = lib().ptx_make_tiles(w, h, samples, fixed_seed, None, 0)
+    out = np.zeros(n, dtype=abi.TILE_DTYPE)
+    lib().ptx_make_tiles(w, h, samples, fixed_seed, out.ctypes.data, n)
+    return out
+
+
+def accumulator_to_image(accum, samples):
+    accum = np.ascontiguousarray(accum, dtype=np.int64)
+    samples = np.ascontiguousarray(samples, dtype=np.uint32)
+    rgb = np.zeros((len(samples), 3), dtype=np.float32)
+    check(lib().ptx_accumulator_to_image(accum.ctypes.data, samples.ctypes.data, len(samples), rgb.ctypes.data))
+    return rgb
+
+
+def tonemap(rgb, exposure=1.0):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((len(rgb), 4), dtype=np.uint8)
+    check(lib().ptx_tonemap(rgb.ctypes.data, len(rgb), exposure, out.ctypes.data))
+    return out

@@ -1,0 +1,29 @@
+// bvh_build.h -- host-side binned-SAH builder: the GPU path's PT::BVH<P>::build.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/ptx.h"
+
+namespace ptx {
+
+struct HostBvh {
+	std::vector<PtxBvhNode> nodes;   // canonical binary tree, root at 0, leaves have l == r
+	std::vector<uint32_t> order;     // order[i] = input index of the i-th BVH-ordered primitive
+	uint64_t clamped = 0;            // primitives whose bin index had to be clamped to [0,7]
+	uint64_t predicate_disagreements = 0;
+	uint64_t dropped = 0;            // primitives under nodes no split separates
+	uint32_t max_depth = 0;          // root = depth 0
+};
+
+// Triangle::bbox (tri_mesh.cpp:10-44) for every triangle of an indexed mesh with 8-float vertices.
+void triangle_boxes(const float* verts, const uint32_t* indices, uint32_t n_tris, std::vector<float>& boxes);
+
+// PT::BVH<P>::build + buildRecursive (bvh.cpp:31-243) over n boxes (6 floats each).
+void build_bvh(const float* boxes, uint32_t n, uint32_t max_leaf_size, HostBvh& out);
+
+// Depth of a tree given as a node array (for injected trees).  Returns false when the
+// array is not a tree rooted at 0 (child index out of range, cycle, range out of bounds).
+bool validate_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_prims, uint32_t& max_depth);
+
+}  // namespace ptx

@@ -1,0 +1,91 @@
+// device_types.h -- memory layouts shared by the host flattener and the gfx950 kernels.
+//
+// Everything here is resident in HBM for the life of a scene.  Sizes are chosen for whole
+// 64-byte lines: one interior-node fetch is one line and brings both children's boxes, so a
+// traversal step costs one dependent memory access, not two.
+#pragma once
+#include <stdint.h>
+
+namespace ptx {
+
+// Child reference.  bit 31 set: leaf, bits [30:4] = first primitive, bits [3:0] = count
+// (0..15).  bit 31 clear: index of an interior node in the same tree's node array.
+constexpr uint32_t REF_LEAF = 0x80000000u;
+constexpr uint32_t MAX_LEAF_PRIMS = 15u;
+constexpr uint32_t MAX_LEAF_START = (1u << 27) - 1u;
+inline constexpr uint32_t make_leaf_ref(uint32_t start, uint32_t count) { return REF_LEAF | (start << 4) | count; }
+
+// Interior node of a binary tree: the boxes of both children and where they lead.
+// PT::BVH keeps one box per node (bvh.h:15-23) and tests it on entry (bvh.cpp:278-286);
+// holding the two child boxes in the parent is the same set of tests, one level earlier.
+struct alignas(64) Node2 {
+	float lmin[3], lmax[3];
+	float rmin[3], rmax[3];
+	uint32_t lref, rref;
+	uint32_t pad[2];
+};
+static_assert(sizeof(Node2) == 64, "one cache line");
+
+// One triangle as the intersector wants it: v0 and the two edges e1 = v1 - v0, e2 = v2 - v0
+// (the subtractions Triangle::hit performs per call, tri_mesh.cpp:57-59, done once in fp32
+// on the host: same operands, same rounding, same bits).
+struct alignas(16) TriGeom {
+	float v0[3], pad0;
+	float e1[3], pad1;
+	float e2[3], pad2;
+};
+static_assert(sizeof(TriGeom) == 48, "three 16-byte loads");
+
+// Shading attributes, read only by the shade stage: per-vertex normals and uvs.
+struct TriAttr {
+	float n0[3], n1[3], n2[3];
+	float uv0[2], uv1[2], uv2[2];
+};
+static_assert(sizeof(TriAttr) == 60, "");
+
+// One mesh (PT::Tri_Mesh): a tree over a range of the scene-wide triangle arrays.
+struct MeshRec {
+	float root_min[3], root_max[3];
+	uint32_t root_ref;      // leaf ref or interior index (relative to node_base)
+	uint32_t node_base;     // first Node2 of this mesh in the scene-wide node array
+	uint32_t tri_base;      // first triangle of this mesh in the scene-wide triangle arrays
+	uint32_t n_tris;
+	uint32_t is_list;       // List<Triangle>: no box test, fold over all n_tris (list.h:25-32)
+	uint32_t pad;
+};
+
+// One PT::Instance (instance.h:15-40).  Matrices column-major, element [col*4+row].
+struct InstRec {
+	float T[16];
+	float iT[16];
+	uint32_t has_transform;
+	int32_t mesh;           // >= 0: MeshRec index; -1: Shapes::Sphere of `radius`
+	float radius;
+	int32_t material;
+};
+
+struct SceneRec {
+	const Node2* nodes;       // all trees' interior nodes
+	const TriGeom* tris;
+	const TriAttr* attrs;
+	const MeshRec* meshes;
+	const InstRec* insts;     // BVH-ordered instance array (Aggregate's BVH<Instance>::primitives)
+	// Top level
+	float top_min[3], top_max[3];
+	uint32_t top_ref;
+	uint32_t top_node_base;
+	uint32_t n_insts;
+	uint32_t top_is_list;     // List<Instance> (--no_bvh)
+	uint32_t mesh_only;       // queries go straight to meshes[0] (PT::Tri_Mesh::hit)
+	uint32_t pad;
+};
+
+// Hit record passed from the extend stage to the shade stage.
+struct HitRec {
+	float distance;
+	uint32_t prim;    // BVH-order index within the mesh, or 0xFFFFFFFF
+	uint32_t inst;    // BVH-order instance index
+	float u, v;
+};
+
+}  // namespace ptx

@@ -1,0 +1,604 @@
+// ptx_api.hip -- implementation of the C ABI declared in include/ptx.h: scene construction
+// (host BVH build, flattening, upload) and the ray-query entry points.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "host_math.h"
+#include "scene.h"
+#include "traverse.hip.h"
+
+namespace ptx {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+	g_last_error = msg;
+	return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+	g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+	return e == hipErrorOutOfMemory ? PTX_ERR_OOM : PTX_ERR_DEVICE;
+}
+
+// ------------------------------------------------------------------ kernels
+template<int MODE>
+__global__ void __launch_bounds__(256) k_trace_closest(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, PtxHit* __restrict__ hits,
+                                                       float* __restrict__ bary, uint32_t* __restrict__ inst) {
+	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float4* rp = reinterpret_cast<const float4*>(rays + i);
+	const float4 a = rp[0], b = rp[1];
+	Ray3 r{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	Stack st;
+	SceneHit h;
+	traverse_scene<MODE, false>(sc, r, st, h);
+	PtxHit out;
+	out.distance = h.distance;
+	out.prim = h.hit ? h.prim : PTX_NO_HIT;
+	hits[i] = out;
+	if (bary) reinterpret_cast<float2*>(bary)[i] = h.hit ? make_float2(h.u, h.v) : make_float2(0.0f, 0.0f);
+	if (inst) inst[i] = h.hit ? h.inst : PTX_NO_HIT;
+}
+
+template<int MODE>
+__global__ void __launch_bounds__(256) k_trace_any(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, uint8_t* __restrict__ occluded) {
+	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float4* rp = reinterpret_cast<const float4*>(rays + i);
+	const float4 a = rp[0], b = rp[1];
+	Ray3 r{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	Stack st;
+	SceneHit h;
+	traverse_scene<MODE, true>(sc, r, st, h);
+	occluded[i] = h.hit ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ flattening
+struct FlatTree {
+	std::vector<Node2> nodes;
+	uint32_t root_ref = make_leaf_ref(0, 0);
+	uint32_t depth = 0;
+};
+
+// Canonical node array -> interior-only Node2 array (children's boxes pulled up into the
+// parent) numbered in depth-first order, leaves folded into child references.
+static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_prims, FlatTree& out) {
+	uint32_t depth = 0;
+	if (!validate_tree(nodes, n_nodes, n_prims, depth)) return fail(PTX_ERR_INVALID, "node array is not a tree rooted at 0 over the given primitives");
+	out.depth = depth;
+	auto leaf_ref = [&](const PtxBvhNode& n, uint32_t& ref) {
+		if (n.size > MAX_LEAF_PRIMS || n.start > MAX_LEAF_START) return false;
+		ref = make_leaf_ref(n.start, n.size);
+		return true;
+	};
+	const char* too_big = "a leaf holds more than 15 primitives (or starts beyond 2^27): not representable in the GPU layout";
+	if (nodes[0].l == nodes[0].r) {
+		if (!leaf_ref(nodes[0], out.root_ref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
+		return PTX_OK;
+	}
+	std::vector<uint32_t> interior_of(n_nodes, 0xFFFFFFFFu);
+	std::vector<uint32_t> stack{0u};
+	uint32_t count = 0;
+	while (!stack.empty()) {  // number interior nodes depth-first, left first
+		uint32_t i = stack.back();
+		stack.pop_back();
+		interior_of[i] = count++;
+		const PtxBvhNode& n = nodes[i];
+		if (nodes[n.r].l != nodes[n.r].r) stack.push_back(n.r);
+		if (nodes[n.l].l != nodes[n.l].r) stack.push_back(n.l);
+	}
+	out.nodes.assign(count, Node2{});
+	for (uint32_t i = 0; i < n_nodes; i++) {
+		if (interior_of[i] == 0xFFFFFFFFu) continue;
+		const PtxBvhNode &n = nodes[i], &l = nodes[n.l], &r = nodes[n.r];
+		Node2& d = out.nodes[interior_of[i]];
+		for (int k = 0; k < 3; k++) d.lmin[k] = l.bmin[k], d.lmax[k] = l.bmax[k], d.rmin[k] = r.bmin[k], d.rmax[k] = r.bmax[k];
+		if (l.l == l.r) {
+			if (!leaf_ref(l, d.lref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
+		} else d.lref = interior_of[n.l];
+		if (r.l == r.r) {
+			if (!leaf_ref(r, d.rref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
+		} else d.rref = interior_of[n.r];
+	}
+	out.root_ref = 0;
+	return PTX_OK;
+}
+
+template<typename T> static int upload(PtxScene* s, const std::vector<T>& v, const T*& dev) {
+	dev = nullptr;
+	if (v.empty()) return PTX_OK;
+	void* p = nullptr;
+	PTX_HIP(hipMalloc(&p, v.size() * sizeof(T)));
+	s->allocations.push_back(p);
+	PTX_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+	dev = static_cast<const T*>(p);
+	return PTX_OK;
+}
+
+static int check_mesh_desc(const PtxMeshDesc& m) {
+	if (m.n_tris && (!m.verts || !m.indices)) return fail(PTX_ERR_INVALID, "mesh with triangles but null verts/indices");
+	for (uint64_t i = 0; i < uint64_t(m.n_tris) * 3; i++)
+		if (m.indices[i] >= m.n_verts) return fail(PTX_ERR_INVALID, "triangle index out of range");
+	const uint32_t max_leaf = m.max_leaf_size ? m.max_leaf_size : 4;
+	if (m.use_bvh && !m.nodes && max_leaf > MAX_LEAF_PRIMS) return fail(PTX_ERR_UNSUPPORTED, "max_leaf_size above 15 is not representable in the GPU layout");
+	return PTX_OK;
+}
+
+struct SceneBuild {
+	std::vector<Node2> nodes;
+	std::vector<TriGeom> tris;
+	std::vector<TriAttr> attrs;
+	std::vector<MeshRec> meshes;
+	std::vector<std::vector<float>> mesh_box;  // Tri_Mesh::bbox per mesh (6 floats)
+};
+
+// PT::Tri_Mesh(const Indexed_Mesh&, bool) -- tri_mesh.cpp:160-177
+static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
+	if (int rc = check_mesh_desc(m)) return rc;
+	MeshRec rec{};
+	rec.node_base = uint32_t(sb.nodes.size());
+	rec.tri_base = uint32_t(sb.tris.size());
+	rec.n_tris = m.n_tris;
+	rec.is_list = m.use_bvh ? 0 : 1;
+	HostBvh bvh;
+	std::vector<float> boxes;
+	triangle_boxes(m.verts, m.indices, m.n_tris, boxes);
+	float mesh_box[6];
+	if (m.nodes) {
+		if (!m.n_nodes) return fail(PTX_ERR_INVALID, "injected tree with zero nodes");
+		bvh.nodes.assign(m.nodes, m.nodes + m.n_nodes);
+		bvh.order.resize(m.n_tris);
+		for (uint32_t i = 0; i < m.n_tris; i++) bvh.order[i] = i;
+	} else if (m.use_bvh) {
+		build_bvh(boxes.data(), m.n_tris, m.max_leaf_size ? m.max_leaf_size : 4, bvh);
+	} else {
+		bvh.order.resize(m.n_tris);
+		for (uint32_t i = 0; i < m.n_tris; i++) bvh.order[i] = i;
+	}
+	if (!rec.is_list) {
+		FlatTree ft;
+		if (int rc = flatten_tree(bvh.nodes.data(), uint32_t(bvh.nodes.size()), m.n_tris, ft)) return rc;
+		bvh.max_depth = ft.depth;
+		rec.root_ref = ft.root_ref;
+		for (int k = 0; k < 3; k++) rec.root_min[k] = bvh.nodes[0].bmin[k], rec.root_max[k] = bvh.nodes[0].bmax[k];
+		sb.nodes.insert(sb.nodes.end(), ft.nodes.begin(), ft.nodes.end());
+		// BVH::bbox (bvh.cpp:433-436)
+		for (int k = 0; k < 3; k++) mesh_box[k] = bvh.nodes[0].bmin[k], mesh_box[3 + k] = bvh.nodes[0].bmax[k];
+	} else {
+		// List::bbox (list.h:17-23): union of the primitive boxes, FLT_MAX box when empty
+		for (int k = 0; k < 3; k++) mesh_box[k] = 3.402823466e+38f, mesh_box[3 + k] = -3.402823466e+38f;
+		for (uint32_t t = 0; t < m.n_tris; t++)
+			for (int k = 0; k < 3; k++) {
+				mesh_box[k] = std::min(mesh_box[k], boxes[size_t(t) * 6 + k]);
+				mesh_box[3 + k] = std::max(mesh_box[3 + k], boxes[size_t(t) * 6 + 3 + k]);
+			}
+	}
+	sb.mesh_box.emplace_back(mesh_box, mesh_box + 6);
+	for (uint32_t i = 0; i < m.n_tris; i++) {
+		const uint32_t t = bvh.order[i];
+		const float* a = m.verts + size_t(m.indices[t * 3 + 0]) * 8;
+		const float* b = m.verts + size_t(m.indices[t * 3 + 1]) * 8;
+		const float* c = m.verts + size_t(m.indices[t * 3 + 2]) * 8;
+		TriGeom g{};
+		TriAttr at{};
+		for (int k = 0; k < 3; k++) {
+			g.v0[k] = a[k];
+			g.e1[k] = b[k] - a[k];   // tri_mesh.cpp:58-59
+			g.e2[k] = c[k] - a[k];
+			at.n0[k] = a[3 + k], at.n1[k] = b[3 + k], at.n2[k] = c[3 + k];
+		}
+		for (int k = 0; k < 2; k++) at.uv0[k] = a[6 + k], at.uv1[k] = b[6 + k], at.uv2[k] = c[6 + k];
+		sb.tris.push_back(g);
+		sb.attrs.push_back(at);
+	}
+	sb.meshes.push_back(rec);
+	s->mesh_bvhs.push_back(std::move(bvh));
+	return PTX_OK;
+}
+
+static int finish_geometry(PtxScene* s, SceneBuild& sb) {
+	if (int rc = upload(s, sb.nodes, s->rec.nodes)) return rc;
+	if (int rc = upload(s, sb.tris, s->rec.tris)) return rc;
+	if (int rc = upload(s, sb.attrs, s->rec.attrs)) return rc;
+	if (int rc = upload(s, sb.meshes, s->rec.meshes)) return rc;
+	s->shade.attrs = s->rec.attrs;
+	s->bytes_nodes = sb.nodes.size() * sizeof(Node2);
+	s->bytes_tris = sb.tris.size() * sizeof(TriGeom);
+	return PTX_OK;
+}
+
+static int open_device(int device, PtxScene** out) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PTX_ERR_NO_DEVICE, "no HIP device visible");
+	if (device < 0 || device >= n) return fail(PTX_ERR_NO_DEVICE, "device index out of range");
+	PTX_HIP(hipSetDevice(device));
+	*out = new PtxScene();
+	(*out)->device = device;
+	return PTX_OK;
+}
+
+static void free_scene(PtxScene* s) {
+	if (!s) return;
+	(void)hipSetDevice(s->device);
+	for (void* p : s->allocations) (void)hipFree(p);
+	for (void* p : s->scratch)
+		if (p) (void)hipFree(p);
+	delete s;
+}
+
+static void mat_copy(float* dst, const float* src) { std::memcpy(dst, src, 16 * sizeof(float)); }
+
+}  // namespace ptx
+
+using namespace ptx;
+
+extern "C" {
+
+const char* ptx_last_error(void) { return g_last_error.c_str(); }
+const char* ptx_version(void) { return "pathtracer_amd 0.1 (gfx950)"; }
+
+int ptx_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+// ------------------------------------------------------------------ host BVH
+int ptx_bvh_build(const float* boxes, uint32_t n, uint32_t max_leaf_size, ptx_bvh_t* out) {
+	if (!out || (n && !boxes) || max_leaf_size == 0) return fail(PTX_ERR_INVALID, "ptx_bvh_build: null argument or max_leaf_size 0");
+	auto* b = new PtxBvh();
+	build_bvh(boxes, n, max_leaf_size, b->bvh);
+	*out = b;
+	return PTX_OK;
+}
+
+int ptx_bvh_build_triangles(const float* verts, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, uint32_t max_leaf_size,
+                            ptx_bvh_t* out) {
+	if (!out || (n_tris && (!verts || !indices)) || max_leaf_size == 0) return fail(PTX_ERR_INVALID, "ptx_bvh_build_triangles: null argument or max_leaf_size 0");
+	for (uint64_t i = 0; i < uint64_t(n_tris) * 3; i++)
+		if (indices[i] >= n_verts) return fail(PTX_ERR_INVALID, "triangle index out of range");
+	std::vector<float> boxes;
+	triangle_boxes(verts, indices, n_tris, boxes);
+	return ptx_bvh_build(boxes.data(), n_tris, max_leaf_size, out);
+}
+
+uint32_t ptx_bvh_num_nodes(ptx_bvh_t b) { return b ? uint32_t(b->bvh.nodes.size()) : 0; }
+uint32_t ptx_bvh_num_prims(ptx_bvh_t b) { return b ? uint32_t(b->bvh.order.size()) : 0; }
+uint32_t ptx_bvh_max_depth(ptx_bvh_t b) { return b ? b->bvh.max_depth : 0; }
+int ptx_bvh_get_nodes(ptx_bvh_t b, PtxBvhNode* out) {
+	if (!b || !out) return fail(PTX_ERR_INVALID, "ptx_bvh_get_nodes: null argument");
+	std::copy(b->bvh.nodes.begin(), b->bvh.nodes.end(), out);
+	return PTX_OK;
+}
+int ptx_bvh_get_order(ptx_bvh_t b, uint32_t* out) {
+	if (!b || !out) return fail(PTX_ERR_INVALID, "ptx_bvh_get_order: null argument");
+	std::copy(b->bvh.order.begin(), b->bvh.order.end(), out);
+	return PTX_OK;
+}
+int ptx_bvh_get_stats(ptx_bvh_t b, uint64_t stats[3]) {
+	if (!b || !stats) return fail(PTX_ERR_INVALID, "ptx_bvh_get_stats: null argument");
+	stats[0] = b->bvh.clamped, stats[1] = b->bvh.predicate_disagreements, stats[2] = b->bvh.dropped;
+	return PTX_OK;
+}
+void ptx_bvh_destroy(ptx_bvh_t b) { delete b; }
+
+// ------------------------------------------------------------------ scenes
+int ptx_scene_create_mesh(int device, const PtxMeshDesc* mesh, ptx_scene_t* out) {
+	if (!mesh || !out) return fail(PTX_ERR_INVALID, "ptx_scene_create_mesh: null argument");
+	PtxScene* s = nullptr;
+	if (int rc = open_device(device, &s)) return rc;
+	SceneBuild sb;
+	int rc = add_mesh(s, sb, *mesh);
+	if (!rc) rc = finish_geometry(s, sb);
+	if (!rc) {
+		s->rec.mesh_only = 1;
+		s->stack_need = s->mesh_bvhs[0].max_depth + 2;
+		if (s->stack_need > uint32_t(STACK_CAP)) rc = fail(PTX_ERR_UNSUPPORTED, "tree deeper than the traversal stack (64 entries)");
+	}
+	if (rc) {
+		free_scene(s);
+		return rc;
+	}
+	*out = s;
+	return PTX_OK;
+}
+
+int ptx_scene_create(int device, const PtxSceneDesc* d, ptx_scene_t* out) {
+	if (!d || !out) return fail(PTX_ERR_INVALID, "ptx_scene_create: null argument");
+	if ((d->n_meshes && !d->meshes) || (d->n_instances && !d->instances) || (d->n_textures && !d->textures) ||
+	    (d->n_materials && !d->materials) || (d->n_delta_lights && !d->delta_lights) || (d->n_env_lights && !d->env_lights))
+		return fail(PTX_ERR_INVALID, "ptx_scene_create: count without array");
+	PtxScene* s = nullptr;
+	if (int rc = open_device(device, &s)) return rc;
+	auto bail = [&](int rc) {
+		free_scene(s);
+		return rc;
+	};
+	SceneBuild sb;
+	for (uint32_t i = 0; i < d->n_meshes; i++)
+		if (int rc = add_mesh(s, sb, d->meshes[i])) return bail(rc);
+
+	// Textures, materials (+ the default Lambertian(0), pathtracer.cpp:240-252), lights.
+	std::vector<TexRec> texs;
+	std::vector<float> texels;
+	for (uint32_t i = 0; i < d->n_textures; i++) {
+		const auto& t = d->textures[i];
+		TexRec r{};
+		r.type = t.type, r.sampler = t.sampler, r.w = t.w, r.h = t.h, r.scale = t.scale;
+		for (int k = 0; k < 3; k++) r.color[k] = t.color[k];
+		if (t.type == PTX_TEX_IMAGE) {
+			if (!t.pixels || !t.w || !t.h) return bail(fail(PTX_ERR_INVALID, "image texture without pixels"));
+			r.pixel_base = uint32_t(texels.size() / 3);
+			texels.insert(texels.end(), t.pixels, t.pixels + size_t(t.w) * t.h * 3);
+		} else if (t.type != PTX_TEX_CONSTANT) return bail(fail(PTX_ERR_INVALID, "unknown texture type"));
+		texs.push_back(r);
+	}
+	const int default_tex = int(texs.size());
+	{
+		TexRec r{};
+		r.type = PTX_TEX_CONSTANT, r.scale = 1.0f;
+		texs.push_back(r);
+	}
+	std::vector<MatRec> mats;
+	for (uint32_t i = 0; i < d->n_materials; i++) {
+		const auto& m = d->materials[i];
+		if (m.type > PTX_MAT_EMISSIVE) return bail(fail(PTX_ERR_INVALID, "unknown material type"));
+		const bool needs_a = m.type != PTX_MAT_REFRACT, needs_b = m.type == PTX_MAT_REFRACT || m.type == PTX_MAT_GLASS;
+		if ((needs_a && (m.tex_a < 0 || m.tex_a >= default_tex)) || (needs_b && (m.tex_b < 0 || m.tex_b >= default_tex)))
+			return bail(fail(PTX_ERR_INVALID, "material references a texture that does not exist"));
+		mats.push_back(MatRec{m.type, m.tex_a, m.tex_b, m.ior});
+	}
+	const int default_mat = int(mats.size());
+	mats.push_back(MatRec{PTX_MAT_LAMBERTIAN, default_tex, -1, 1.5f});
+	std::vector<DeltaLightRec> dls;
+	for (uint32_t i = 0; i < d->n_delta_lights; i++) {
+		const auto& l = d->delta_lights[i];
+		if (l.type > PTX_LIGHT_SPOT) return bail(fail(PTX_ERR_INVALID, "unknown delta light type"));
+		DeltaLightRec r{};
+		r.type = l.type, r.intensity = l.intensity, r.inner_angle = l.inner_angle, r.outer_angle = l.outer_angle;
+		for (int k = 0; k < 3; k++) r.color[k] = l.color[k];
+		Mat4f T;
+		mat_copy(T.m, l.T);
+		Mat4f iT = mat4_inverse(T);
+		mat_copy(r.T, T.m), mat_copy(r.iT, iT.m);
+		r.has_transform = mat4_is_identity(T) ? 0 : 1;
+		dls.push_back(r);
+	}
+	std::vector<EnvLightRec> els;
+	for (uint32_t i = 0; i < d->n_env_lights; i++) {
+		const auto& l = d->env_lights[i];
+		if (l.type > PTX_ENV_SPHERE || l.tex < 0 || l.tex >= default_tex) return bail(fail(PTX_ERR_INVALID, "bad environment light"));
+		els.push_back(EnvLightRec{l.type, l.tex});
+	}
+
+	// Instances (instance.h:17-30) and the top-level tree (pathtracer.cpp:381-385).
+	std::vector<InstRec> insts_in;
+	std::vector<float> inst_boxes;
+	uint32_t deepest_mesh = 0;
+	for (uint32_t i = 0; i < d->n_instances; i++) {
+		const auto& in = d->instances[i];
+		if (in.mesh >= int32_t(d->n_meshes) || in.material >= int32_t(d->n_materials)) return bail(fail(PTX_ERR_INVALID, "instance references a mesh or material that does not exist"));
+		InstRec r{};
+		Mat4f T;
+		mat_copy(T.m, in.T);
+		Mat4f iT = mat4_inverse(T);
+		mat_copy(r.T, T.m), mat_copy(r.iT, iT.m);
+		r.has_transform = mat4_is_identity(T) ? 0 : 1;
+		r.mesh = in.mesh < 0 ? -1 : in.mesh;
+		r.radius = in.sphere_radius;
+		r.material = in.material < 0 ? default_mat : in.material;
+		float box[6];
+		if (r.mesh >= 0) {
+			std::copy(sb.mesh_box[size_t(r.mesh)].begin(), sb.mesh_box[size_t(r.mesh)].end(), box);
+			deepest_mesh = std::max(deepest_mesh, s->mesh_bvhs[size_t(r.mesh)].max_depth);
+		} else {
+			for (int k = 0; k < 3; k++) box[k] = -r.radius, box[3 + k] = r.radius;   // shape.cpp:14-19
+		}
+		if (r.has_transform) box_transform(T, box);
+		inst_boxes.insert(inst_boxes.end(), box, box + 6);
+		insts_in.push_back(r);
+	}
+	std::vector<InstRec> insts(insts_in.size());
+	s->rec.top_is_list = d->use_bvh ? 0 : 1;
+	s->rec.n_insts = d->n_instances;
+	if (d->use_bvh) {
+		build_bvh(inst_boxes.data(), d->n_instances, 1, s->top_bvh);
+		FlatTree ft;
+		if (int rc = flatten_tree(s->top_bvh.nodes.data(), uint32_t(s->top_bvh.nodes.size()), d->n_instances, ft)) return bail(rc);
+		s->top_bvh.max_depth = ft.depth;
+		s->rec.top_ref = ft.root_ref;
+		s->rec.top_node_base = uint32_t(sb.nodes.size());
+		for (int k = 0; k < 3; k++) s->rec.top_min[k] = s->top_bvh.nodes[0].bmin[k], s->rec.top_max[k] = s->top_bvh.nodes[0].bmax[k];
+		sb.nodes.insert(sb.nodes.end(), ft.nodes.begin(), ft.nodes.end());
+	} else {
+		s->top_bvh.order.resize(d->n_instances);
+		for (uint32_t i = 0; i < d->n_instances; i++) s->top_bvh.order[i] = i;
+	}
+	for (uint32_t i = 0; i < d->n_instances; i++) insts[i] = insts_in[s->top_bvh.order[i]];
+	s->stack_need = s->top_bvh.max_depth + deepest_mesh + 3;
+	if (s->stack_need > uint32_t(STACK_CAP)) return bail(fail(PTX_ERR_UNSUPPORTED, "trees deeper than the traversal stack (64 entries)"));
+
+	if (int rc = finish_geometry(s, sb)) return bail(rc);
+	if (int rc = upload(s, insts, s->rec.insts)) return bail(rc);
+	if (int rc = upload(s, texs, s->shade.textures)) return bail(rc);
+	if (int rc = upload(s, texels, s->shade.texels)) return bail(rc);
+	if (int rc = upload(s, mats, s->shade.materials)) return bail(rc);
+	if (int rc = upload(s, dls, s->shade.delta_lights)) return bail(rc);
+	if (int rc = upload(s, els, s->shade.env_lights)) return bail(rc);
+	s->shade.n_delta_lights = uint32_t(dls.size());
+	s->shade.n_env_lights = uint32_t(els.size());
+	s->shade.fresnel_mode = d->fresnel_mode;
+	*out = s;
+	return PTX_OK;
+}
+
+void ptx_scene_destroy(ptx_scene_t s) { free_scene(s); }
+
+int ptx_scene_set_stream(ptx_scene_t s, void* hip_stream) {
+	if (!s) return fail(PTX_ERR_INVALID, "ptx_scene_set_stream: null scene");
+	s->stream = static_cast<hipStream_t>(hip_stream);
+	return PTX_OK;
+}
+
+uint32_t ptx_scene_mesh_num_nodes(ptx_scene_t s, uint32_t mesh) {
+	return (s && mesh < s->mesh_bvhs.size()) ? uint32_t(s->mesh_bvhs[mesh].nodes.size()) : 0;
+}
+int ptx_scene_mesh_get_nodes(ptx_scene_t s, uint32_t mesh, PtxBvhNode* out) {
+	if (!s || !out || mesh >= s->mesh_bvhs.size()) return fail(PTX_ERR_INVALID, "ptx_scene_mesh_get_nodes: bad argument");
+	std::copy(s->mesh_bvhs[mesh].nodes.begin(), s->mesh_bvhs[mesh].nodes.end(), out);
+	return PTX_OK;
+}
+int ptx_scene_mesh_get_order(ptx_scene_t s, uint32_t mesh, uint32_t* out) {
+	if (!s || !out || mesh >= s->mesh_bvhs.size()) return fail(PTX_ERR_INVALID, "ptx_scene_mesh_get_order: bad argument");
+	std::copy(s->mesh_bvhs[mesh].order.begin(), s->mesh_bvhs[mesh].order.end(), out);
+	return PTX_OK;
+}
+int ptx_scene_get_instance_order(ptx_scene_t s, uint32_t* out) {
+	if (!s || !out) return fail(PTX_ERR_INVALID, "ptx_scene_get_instance_order: bad argument");
+	std::copy(s->top_bvh.order.begin(), s->top_bvh.order.end(), out);
+	return PTX_OK;
+}
+
+int ptx_get_counters(ptx_scene_t s, PtxCounters* out) {
+	if (!s || !out) return fail(PTX_ERR_INVALID, "ptx_get_counters: null argument");
+	*out = s->counters;
+	return PTX_OK;
+}
+
+// ------------------------------------------------------------------ ray queries
+static int ensure_scratch(PtxScene* s, int slot, size_t bytes) {
+	if (s->scratch_bytes[slot] >= bytes) return PTX_OK;
+	if (s->scratch[slot]) PTX_HIP(hipFree(s->scratch[slot]));
+	s->scratch[slot] = nullptr, s->scratch_bytes[slot] = 0;
+	PTX_HIP(hipMalloc(&s->scratch[slot], bytes));
+	s->scratch_bytes[slot] = bytes;
+	return PTX_OK;
+}
+
+int ptx_trace_closest(ptx_scene_t s, const PtxRay* rays, uint64_t n, PtxHit* hits, float* bary, uint32_t* inst, uint32_t flags) {
+	if (!s || (n && (!rays || !hits))) return fail(PTX_ERR_INVALID, "ptx_trace_closest: null argument");
+	if ((flags & PTX_ASYNC) && !(flags & PTX_MEM_DEVICE)) return fail(PTX_ERR_INVALID, "PTX_ASYNC needs PTX_MEM_DEVICE");
+	if (n == 0) return PTX_OK;
+	if (n > (uint64_t(1) << 39)) return fail(PTX_ERR_INVALID, "ray count too large for one launch");
+	PTX_HIP(hipSetDevice(s->device));
+	const PtxRay* d_rays = rays;
+	PtxHit* d_hits = hits;
+	float* d_bary = bary;
+	uint32_t* d_inst = inst;
+	const bool host = !(flags & PTX_MEM_DEVICE);
+	if (host) {
+		if (int rc = ensure_scratch(s, 0, n * sizeof(PtxRay))) return rc;
+		if (int rc = ensure_scratch(s, 1, n * sizeof(PtxHit))) return rc;
+		if (bary)
+			if (int rc = ensure_scratch(s, 2, n * 2 * sizeof(float))) return rc;
+		if (inst)
+			if (int rc = ensure_scratch(s, 3, n * sizeof(uint32_t))) return rc;
+		PTX_HIP(hipMemcpyAsync(s->scratch[0], rays, n * sizeof(PtxRay), hipMemcpyHostToDevice, s->stream));
+		d_rays = static_cast<const PtxRay*>(s->scratch[0]);
+		d_hits = static_cast<PtxHit*>(s->scratch[1]);
+		d_bary = bary ? static_cast<float*>(s->scratch[2]) : nullptr;
+		d_inst = inst ? static_cast<uint32_t*>(s->scratch[3]) : nullptr;
+	}
+	const dim3 block(256), grid(uint32_t((n + 255) / 256));
+	if ((flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED)
+		hipLaunchKernelGGL(k_trace_closest<MODE_CULLED>, grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
+	else
+		hipLaunchKernelGGL(k_trace_closest<MODE_REFERENCE>, grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
+	PTX_HIP(hipGetLastError());
+	s->counters.rays_closest += n;
+	if (host) {
+		PTX_HIP(hipMemcpyAsync(hits, d_hits, n * sizeof(PtxHit), hipMemcpyDeviceToHost, s->stream));
+		if (bary) PTX_HIP(hipMemcpyAsync(bary, d_bary, n * 2 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+		if (inst) PTX_HIP(hipMemcpyAsync(inst, d_inst, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+	}
+	if (!(flags & PTX_ASYNC)) PTX_HIP(hipStreamSynchronize(s->stream));
+	return PTX_OK;
+}
+
+int ptx_trace_any(ptx_scene_t s, const PtxRay* rays, uint64_t n, uint8_t* occluded, uint32_t flags) {
+	if (!s || (n && (!rays || !occluded))) return fail(PTX_ERR_INVALID, "ptx_trace_any: null argument");
+	if ((flags & PTX_ASYNC) && !(flags & PTX_MEM_DEVICE)) return fail(PTX_ERR_INVALID, "PTX_ASYNC needs PTX_MEM_DEVICE");
+	if (n == 0) return PTX_OK;
+	if (n > (uint64_t(1) << 39)) return fail(PTX_ERR_INVALID, "ray count too large for one launch");
+	PTX_HIP(hipSetDevice(s->device));
+	const PtxRay* d_rays = rays;
+	uint8_t* d_occ = occluded;
+	const bool host = !(flags & PTX_MEM_DEVICE);
+	if (host) {
+		if (int rc = ensure_scratch(s, 0, n * sizeof(PtxRay))) return rc;
+		if (int rc = ensure_scratch(s, 1, n)) return rc;
+		PTX_HIP(hipMemcpyAsync(s->scratch[0], rays, n * sizeof(PtxRay), hipMemcpyHostToDevice, s->stream));
+		d_rays = static_cast<const PtxRay*>(s->scratch[0]);
+		d_occ = static_cast<uint8_t*>(s->scratch[1]);
+	}
+	const dim3 block(256), grid(uint32_t((n + 255) / 256));
+	if ((flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED)
+		hipLaunchKernelGGL(k_trace_any<MODE_CULLED>, grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
+	else
+		hipLaunchKernelGGL(k_trace_any<MODE_REFERENCE>, grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
+	PTX_HIP(hipGetLastError());
+	s->counters.rays_any += n;
+	if (host) PTX_HIP(hipMemcpyAsync(occluded, d_occ, n, hipMemcpyDeviceToHost, s->stream));
+	if (!(flags & PTX_ASYNC)) PTX_HIP(hipStreamSynchronize(s->stream));
+	return PTX_OK;
+}
+
+// ------------------------------------------------------------------ tiles, accumulator, tonemap (host)
+uint32_t ptx_make_tiles(uint32_t W, uint32_t H, uint32_t samples, uint32_t fixed_seed, PtxTile* out, uint32_t cap) {
+	// pathtracer.cpp:522-563
+	constexpr uint32_t tile_w = 100, tile_h = 100, tile_s = 50;
+	std::mt19937 seeds(fixed_seed);
+	std::vector<PtxTile> tiles;
+	for (uint32_t y = 0; y < H; y += tile_h)
+		for (uint32_t x = 0; x < W; x += tile_w)
+			for (uint32_t sb = 0; sb < samples; sb += tile_s) {
+				PtxTile t;
+				t.seed = uint32_t(seeds());
+				t.x_begin = x, t.x_end = std::min(x + tile_w, W);
+				t.y_begin = y, t.y_end = std::min(y + tile_h, H);
+				t.s_begin = sb, t.s_end = std::min(sb + tile_s, samples);
+				tiles.push_back(t);
+			}
+	auto centre_distance = [&](const PtxTile& t) {
+		const float dx = 0.5f * (t.x_begin + t.x_end) - W * 0.5f, dy = 0.5f * (t.y_begin + t.y_end) - H * 0.5f;
+		return std::sqrt(dx * dx + dy * dy);
+	};
+	std::stable_sort(tiles.begin(), tiles.end(), [&](const PtxTile& a, const PtxTile& b) {
+		const float da = centre_distance(a), db = centre_distance(b);
+		if (da != db) return da < db;
+		return a.s_begin < b.s_begin;
+	});
+	if (out)
+		for (size_t i = 0; i < tiles.size() && i < cap; i++) out[i] = tiles[i];
+	return uint32_t(tiles.size());
+}
+
+int ptx_accumulator_to_image(const int64_t* accum_rgb, const uint32_t* samples, uint64_t n_pixels, float* rgb) {
+	if (n_pixels && (!accum_rgb || !samples || !rgb)) return fail(PTX_ERR_INVALID, "ptx_accumulator_to_image: null argument");
+	for (uint64_t i = 0; i < n_pixels; i++)
+		for (int c = 0; c < 3; c++)
+			rgb[i * 3 + c] = samples[i] > 0 ? float(accum_rgb[i * 3 + c] / double(1ll << 24) / double(samples[i])) : 0.0f;
+	return PTX_OK;
+}
+
+int ptx_tonemap(const float* rgb, uint64_t n_pixels, float exposure, uint8_t* rgba) {
+	if (n_pixels && (!rgb || !rgba)) return fail(PTX_ERR_INVALID, "ptx_tonemap: null argument");
+	auto srgb = [](float f) { return f > 0.0031308f ? 1.055f * (std::pow(f, (1.0f / 2.4f))) - 0.055f : f * 12.92f; };
+	for (uint64_t i = 0; i < n_pixels; i++) {
+		for (int c = 0; c < 3; c++) {
+			const float v = 1.0f - std::exp(-rgb[i * 3 + c] * exposure);
+			rgba[i * 4 + c] = static_cast<uint8_t>(std::round(srgb(v) * 255.0f));
+		}
+		rgba[i * 4 + 3] = 255;
+	}
+	return PTX_OK;
+}
+
+}  // extern "C"

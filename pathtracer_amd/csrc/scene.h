@@ -1,0 +1,76 @@
+// scene.h -- the host-side scene object behind ptx_scene_t.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ptx.h"
+#include "bvh_build.h"
+#include "device_types.h"
+
+namespace ptx {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define PTX_HIP(call)                                        \
+	do {                                                     \
+		hipError_t e_ = (call);                              \
+		if (e_ != hipSuccess) return ptx::hip_fail(e_, #call); \
+	} while (0)
+
+// Material / texture / light tables as the shade stage reads them.
+struct TexRec {
+	uint32_t type, sampler, w, h;
+	float color[3], scale;
+	uint32_t pixel_base;   // first texel (float3) in the scene-wide texel array
+	uint32_t pad[3];
+};
+struct MatRec {
+	uint32_t type;
+	int32_t tex_a, tex_b;
+	float ior;
+};
+struct DeltaLightRec {
+	uint32_t type, has_transform;
+	float color[3], intensity, inner_angle, outer_angle;
+	float T[16], iT[16];
+};
+struct EnvLightRec {
+	uint32_t type;
+	int32_t tex;
+};
+
+struct ShadeTables {
+	const TriAttr* attrs;
+	const TexRec* textures;
+	const float* texels;
+	const MatRec* materials;
+	const DeltaLightRec* delta_lights;
+	const EnvLightRec* env_lights;
+	uint32_t n_delta_lights, n_env_lights, fresnel_mode, pad;
+};
+
+}  // namespace ptx
+
+struct PtxBvh {
+	ptx::HostBvh bvh;
+};
+
+struct PtxScene {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	ptx::SceneRec rec{};            // device pointers inside
+	ptx::ShadeTables shade{};
+	std::vector<void*> allocations; // everything hipMalloc'ed for this scene
+	std::vector<ptx::HostBvh> mesh_bvhs;
+	ptx::HostBvh top_bvh;
+	uint32_t stack_need = 0;        // deepest stack a traversal of this scene can need
+	uint64_t bytes_nodes = 0, bytes_tris = 0;
+	PtxCounters counters{};
+	// Scratch grown on demand (host-pointer calls, render state).
+	void* scratch[8] = {};
+	size_t scratch_bytes[8] = {};
+};

@@ -130,6 +130,12 @@ def main():
     mismatch_any = int((occ != occ_ref).sum().item())
     hit_fraction = float((hits_ref[:, 1] != -1).float().mean().item())
     headline_mode = abi.PTX_TRAVERSE_CULLED if mismatch_closest == 0 else abi.PTX_TRAVERSE_REFERENCE
+    if mismatch_closest and rank == 0:   # leave evidence for whoever debugs it
+        bad = torch.nonzero((hits != hits_ref).any(dim=1)).flatten()[:16].cpu().numpy()
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "closest_mismatch.json"), "w") as f:
+            json.dump({"rays": [int(b) for b in bad], "culled": hits[bad].cpu().numpy().tolist(), "reference": hits_ref[bad].cpu().numpy().tolist(),
+                       "ray_data": rays_h[bad].view(np.float32).reshape(-1, 8).tolist()}, f)
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -160,6 +166,7 @@ def main():
 
     # secondary figures (not part of `value`)
     _, ref_ms = timed(lambda: closest(abi.PTX_TRAVERSE_REFERENCE, hits_ref), max(1, args.steps // 3), 1)
+    _, cul_ms = timed(lambda: closest(abi.PTX_TRAVERSE_CULLED, hits), max(1, args.steps // 3), 1)
     _, any_ms = timed(lambda: anyhit(abi.PTX_TRAVERSE_CULLED if mismatch_any == 0 else abi.PTX_TRAVERSE_REFERENCE, occ), args.steps, 1)
 
     result = {
@@ -172,6 +179,7 @@ def main():
         "parity": {"culled_vs_reference_mode_mismatches": mismatch_closest, "anyhit_culled_vs_reference_mismatches": mismatch_any,
                    "rays_checked": n, "hit_fraction": round(hit_fraction, 4)},
         "reference_mode_mrays_per_s": round(n / ref_ms / 1e3, 2),
+        "culled_mode_mrays_per_s": round(n / cul_ms / 1e3, 2),
         "anyhit_mrays_per_s": round(n / any_ms / 1e3, 2),
     }
 

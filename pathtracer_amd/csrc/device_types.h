@@ -8,11 +8,17 @@
 
 namespace ptx {
 
-// Child reference.  bit 31 set: leaf, bits [30:4] = first primitive, bits [3:0] = count
-// (0..15).  bit 31 clear: index of an interior node in the same tree's node array.
+// Child reference.  bit 31 set: leaf, bits [29:4] = first primitive, bits [3:0] = count
+// (0..15).  bit 31 clear: bits [29:0] = index of an interior node in the same tree's node
+// array.  bit 30 (either kind): the subtree holds a primitive that sticks out of the
+// subtree's box, so the box's entry distance is not a lower bound for the hits inside and
+// the culled traversal modes must not skip it on distance.  (The reference builder can
+// leave a primitive in a range whose box was built without it, bvh.cpp:191-221.)
 constexpr uint32_t REF_LEAF = 0x80000000u;
+constexpr uint32_t REF_NOCULL = 0x40000000u;
+constexpr uint32_t REF_INDEX_MASK = 0x3FFFFFFFu;
 constexpr uint32_t MAX_LEAF_PRIMS = 15u;
-constexpr uint32_t MAX_LEAF_START = (1u << 27) - 1u;
+constexpr uint32_t MAX_LEAF_START = (1u << 26) - 1u;
 inline constexpr uint32_t make_leaf_ref(uint32_t start, uint32_t count) { return REF_LEAF | (start << 4) | count; }
 
 // Interior node of a binary tree: the boxes of both children and where they lead.

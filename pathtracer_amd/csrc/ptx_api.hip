@@ -65,22 +65,60 @@ struct FlatTree {
 	std::vector<Node2> nodes;
 	uint32_t root_ref = make_leaf_ref(0, 0);
 	uint32_t depth = 0;
+	uint32_t n_nocull = 0;   // child references marked REF_NOCULL
 };
 
 // Canonical node array -> interior-only Node2 array (children's boxes pulled up into the
 // parent) numbered in depth-first order, leaves folded into child references.
-static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_prims, FlatTree& out) {
+// prim_boxes (6 floats per primitive, in BVH order) lets the flattener find subtrees whose
+// box does not contain all their primitives and mark the references to them REF_NOCULL.
+static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_prims, const float* prim_boxes, FlatTree& out) {
 	uint32_t depth = 0;
 	if (!validate_tree(nodes, n_nodes, n_prims, depth)) return fail(PTX_ERR_INVALID, "node array is not a tree rooted at 0 over the given primitives");
 	out.depth = depth;
-	auto leaf_ref = [&](const PtxBvhNode& n, uint32_t& ref) {
+	// Post-order pass: the box the subtree's primitives really occupy, and whether it pokes
+	// out of the node's stored box.
+	std::vector<uint8_t> sticks_out(n_nodes, 0);
+	{
+		std::vector<float> real(size_t(n_nodes) * 6);
+		std::vector<uint32_t> order;   // nodes in an order where children follow parents
+		order.reserve(n_nodes);
+		std::vector<uint32_t> stack{0u};
+		while (!stack.empty()) {
+			uint32_t i = stack.back();
+			stack.pop_back();
+			order.push_back(i);
+			if (nodes[i].l != nodes[i].r) stack.push_back(nodes[i].l), stack.push_back(nodes[i].r);
+		}
+		for (size_t k = order.size(); k-- > 0;) {
+			const uint32_t i = order[k];
+			const PtxBvhNode& n = nodes[i];
+			float* b = &real[size_t(i) * 6];
+			for (int a = 0; a < 3; a++) b[a] = 3.402823466e+38f, b[3 + a] = -3.402823466e+38f;
+			auto grow = [&](const float* o) {
+				for (int a = 0; a < 3; a++) b[a] = std::min(b[a], o[a]), b[3 + a] = std::max(b[3 + a], o[3 + a]);
+			};
+			if (n.l == n.r) {
+				for (uint32_t p = n.start; p < n.start + n.size; p++) grow(prim_boxes + size_t(p) * 6);
+			} else {
+				grow(&real[size_t(n.l) * 6]);
+				grow(&real[size_t(n.r) * 6]);
+			}
+			bool out_of_box = false;
+			for (int a = 0; a < 3; a++) out_of_box |= (b[a] < n.bmin[a]) || (b[3 + a] > n.bmax[a]);
+			const bool holds_any = n.l != n.r || n.size > 0;
+			sticks_out[i] = (holds_any && out_of_box) ? 1 : 0;
+		}
+	}
+	auto leaf_ref = [&](uint32_t i, uint32_t& ref) {
+		const PtxBvhNode& n = nodes[i];
 		if (n.size > MAX_LEAF_PRIMS || n.start > MAX_LEAF_START) return false;
-		ref = make_leaf_ref(n.start, n.size);
+		ref = make_leaf_ref(n.start, n.size) | (sticks_out[i] ? REF_NOCULL : 0u);
 		return true;
 	};
-	const char* too_big = "a leaf holds more than 15 primitives (or starts beyond 2^27): not representable in the GPU layout";
+	const char* too_big = "a leaf holds more than 15 primitives (or starts beyond 2^26): not representable in the GPU layout";
 	if (nodes[0].l == nodes[0].r) {
-		if (!leaf_ref(nodes[0], out.root_ref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
+		if (!leaf_ref(0, out.root_ref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
 		return PTX_OK;
 	}
 	std::vector<uint32_t> interior_of(n_nodes, 0xFFFFFFFFu);
@@ -94,6 +132,7 @@ static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_pr
 		if (nodes[n.r].l != nodes[n.r].r) stack.push_back(n.r);
 		if (nodes[n.l].l != nodes[n.l].r) stack.push_back(n.l);
 	}
+	if (count > REF_INDEX_MASK) return fail(PTX_ERR_UNSUPPORTED, "more than 2^30 interior nodes");
 	out.nodes.assign(count, Node2{});
 	for (uint32_t i = 0; i < n_nodes; i++) {
 		if (interior_of[i] == 0xFFFFFFFFu) continue;
@@ -101,11 +140,12 @@ static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_pr
 		Node2& d = out.nodes[interior_of[i]];
 		for (int k = 0; k < 3; k++) d.lmin[k] = l.bmin[k], d.lmax[k] = l.bmax[k], d.rmin[k] = r.bmin[k], d.rmax[k] = r.bmax[k];
 		if (l.l == l.r) {
-			if (!leaf_ref(l, d.lref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
-		} else d.lref = interior_of[n.l];
+			if (!leaf_ref(n.l, d.lref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
+		} else d.lref = interior_of[n.l] | (sticks_out[n.l] ? REF_NOCULL : 0u);
 		if (r.l == r.r) {
-			if (!leaf_ref(r, d.rref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
-		} else d.rref = interior_of[n.r];
+			if (!leaf_ref(n.r, d.rref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
+		} else d.rref = interior_of[n.r] | (sticks_out[n.r] ? REF_NOCULL : 0u);
+		out.n_nocull += (d.lref & REF_NOCULL ? 1 : 0) + (d.rref & REF_NOCULL ? 1 : 0);
 	}
 	out.root_ref = 0;
 	return PTX_OK;
@@ -164,7 +204,9 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 	}
 	if (!rec.is_list) {
 		FlatTree ft;
-		if (int rc = flatten_tree(bvh.nodes.data(), uint32_t(bvh.nodes.size()), m.n_tris, ft)) return rc;
+		std::vector<float> ordered(boxes.size());
+		for (uint32_t i = 0; i < m.n_tris; i++) std::copy(&boxes[size_t(bvh.order[i]) * 6], &boxes[size_t(bvh.order[i]) * 6] + 6, &ordered[size_t(i) * 6]);
+		if (int rc = flatten_tree(bvh.nodes.data(), uint32_t(bvh.nodes.size()), m.n_tris, ordered.data(), ft)) return rc;
 		bvh.max_depth = ft.depth;
 		rec.root_ref = ft.root_ref;
 		for (int k = 0; k < 3; k++) rec.root_min[k] = bvh.nodes[0].bmin[k], rec.root_max[k] = bvh.nodes[0].bmax[k];
@@ -411,7 +453,10 @@ int ptx_scene_create(int device, const PtxSceneDesc* d, ptx_scene_t* out) {
 	if (d->use_bvh) {
 		build_bvh(inst_boxes.data(), d->n_instances, 1, s->top_bvh);
 		FlatTree ft;
-		if (int rc = flatten_tree(s->top_bvh.nodes.data(), uint32_t(s->top_bvh.nodes.size()), d->n_instances, ft)) return bail(rc);
+		std::vector<float> ordered(inst_boxes.size());
+		for (uint32_t i = 0; i < d->n_instances; i++)
+			std::copy(&inst_boxes[size_t(s->top_bvh.order[i]) * 6], &inst_boxes[size_t(s->top_bvh.order[i]) * 6] + 6, &ordered[size_t(i) * 6]);
+		if (int rc = flatten_tree(s->top_bvh.nodes.data(), uint32_t(s->top_bvh.nodes.size()), d->n_instances, ordered.data(), ft)) return bail(rc);
 		s->top_bvh.max_depth = ft.depth;
 		s->rec.top_ref = ft.root_ref;
 		s->rec.top_node_base = uint32_t(sb.nodes.size());

@@ -126,7 +126,7 @@ __device__ __forceinline__ void traverse_mesh(const SceneRec& sc, const MeshRec&
 	uint32_t ref = mesh.root_ref;
 	for (;;) {
 		if (ref & REF_LEAF) {
-			const uint32_t first = (ref & ~REF_LEAF) >> 4, count = ref & 15u;
+			const uint32_t first = (ref & REF_INDEX_MASK) >> 4, count = ref & 15u;
 			for (uint32_t i = first; i < first + count; i++) {
 				float d, t, u, v;
 				if (triangle_test(tris, i, r, d, t, u, v)) {
@@ -138,7 +138,7 @@ __device__ __forceinline__ void traverse_mesh(const SceneRec& sc, const MeshRec&
 				}
 			}
 		} else {
-			const float4* p = reinterpret_cast<const float4*>(nodes + ref);
+			const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
 			const float4 n0 = p[0], n1 = p[1], n2 = p[2];
 			const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
 			float tl, tr;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void traverse_mesh(const SceneRec& sc, const MeshRec&
 				}
 			} else {
 				const float limit = ANY ? r.tmax * CULL_SCALE + CULL_BIAS : (cur.hit ? cur.distance * CULL_SCALE + CULL_BIAS : INFINITY);
-				const bool gl = hl && !(tl > limit), gr = hr && !(tr > limit);
+				const bool gl = hl && ((kids.x & REF_NOCULL) || !(tl > limit)), gr = hr && ((kids.y & REF_NOCULL) || !(tr > limit));
 				if (gl && gr) {
 					const bool left_first = !(tr < tl);
 					st.ref[sp] = left_first ? kids.y : kids.x;
@@ -179,7 +179,7 @@ __device__ __forceinline__ void traverse_mesh(const SceneRec& sc, const MeshRec&
 				if (cur.hit && !(cur.distance >= 0.0f)) continue;   // bvh.cpp:337-339
 				break;
 			} else {
-				if (!ANY && cur.hit && st.tnear[sp] > cur.distance * CULL_SCALE + CULL_BIAS) continue;
+				if (!ANY && cur.hit && !(ref & REF_NOCULL) && st.tnear[sp] > cur.distance * CULL_SCALE + CULL_BIAS) continue;
 				break;
 			}
 		}
@@ -305,7 +305,7 @@ __device__ __forceinline__ void traverse_scene(const SceneRec& sc, const Ray3& r
 	uint32_t ref = sc.top_ref;
 	for (;;) {
 		if (ref & REF_LEAF) {
-			const uint32_t first = (ref & ~REF_LEAF) >> 4, count = ref & 15u;
+			const uint32_t first = (ref & REF_INDEX_MASK) >> 4, count = ref & 15u;
 			for (uint32_t i = first; i < first + count; i++) {
 				SceneHit h;
 				if (instance_hit<MODE, ANY>(sc, i, r, st, sp, h)) {
@@ -316,7 +316,7 @@ __device__ __forceinline__ void traverse_scene(const SceneRec& sc, const Ray3& r
 				}
 			}
 		} else {
-			const float4* p = reinterpret_cast<const float4*>(nodes + ref);
+			const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
 			const float4 n0 = p[0], n1 = p[1], n2 = p[2];
 			const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
 			float tl, tr;
@@ -334,7 +334,7 @@ __device__ __forceinline__ void traverse_scene(const SceneRec& sc, const Ray3& r
 				}
 			} else {
 				const float limit = ANY ? r.tmax * CULL_SCALE + CULL_BIAS : (cur.hit ? cur.distance * CULL_SCALE + CULL_BIAS : INFINITY);
-				const bool gl = hl && !(tl > limit), gr = hr && !(tr > limit);
+				const bool gl = hl && ((kids.x & REF_NOCULL) || !(tl > limit)), gr = hr && ((kids.y & REF_NOCULL) || !(tr > limit));
 				if (gl && gr) {
 					const bool left_first = !(tr < tl);
 					st.ref[sp] = left_first ? kids.y : kids.x;
@@ -355,7 +355,7 @@ __device__ __forceinline__ void traverse_scene(const SceneRec& sc, const Ray3& r
 				if (cur.hit && !(cur.distance >= 0.0f)) continue;
 				break;
 			} else {
-				if (!ANY && cur.hit && st.tnear[sp] > cur.distance * CULL_SCALE + CULL_BIAS) continue;
+				if (!ANY && cur.hit && !(ref & REF_NOCULL) && st.tnear[sp] > cur.distance * CULL_SCALE + CULL_BIAS) continue;
 				break;
 			}
 		}

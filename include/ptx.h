@@ -55,7 +55,10 @@ enum {
 	 */
 	PTX_TRAVERSE_REFERENCE = 0u << 4,
 	PTX_TRAVERSE_CULLED = 1u << 4,
-	PTX_TRAVERSE_MASK = 3u << 4
+	PTX_TRAVERSE_MASK = 3u << 4,
+	/* Run the one-ray-per-lane kernel even where the replenishing kernel applies (A/B timing and
+	 * tests; results are identical). */
+	PTX_NO_PERSISTENT = 1u << 8
 };
 
 /* ------------------------------------------------------------------ rays and hits */
@@ -219,6 +222,14 @@ int ptx_trace_closest(ptx_scene_t scene, const PtxRay* rays, uint64_t n, PtxHit*
  * `scene.hit(shadow_ray).hit` (pathtracer.cpp:657-660).  occluded[i] = that boolean,
  * computed with early exit on the first accepted triangle. */
 int ptx_trace_any(ptx_scene_t scene, const PtxRay* rays, uint64_t n, uint8_t* occluded, uint32_t flags);
+
+/* Diagnostics (no counterpart in the reference).  ptx_trace_closest_stats: the closest-hit
+ * traversal instrumented; stats3[3*i + {0,1,2}] = interior nodes fetched (two box tests each),
+ * leaves entered, triangles tested for ray i.  ptx_selftest_division: runs `pairs` operand
+ * pairs through the traversal's short division form and the IEEE quotient on the device and
+ * reports how many differ in any bit. */
+int ptx_trace_closest_stats(ptx_scene_t scene, const PtxRay* rays, uint64_t n, uint32_t* stats3, uint32_t flags);
+int ptx_selftest_division(int device, uint64_t pairs, uint64_t seed, uint64_t* mismatches);
 
 /* ------------------------------------------------------------------ rendering */
 typedef struct PtxCamera {                   /* scene/camera.h:12-30 + Pathtracer::set_camera (pathtracer.cpp:389-396) */

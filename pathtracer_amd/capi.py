@@ -54,6 +54,8 @@ def lib():
     L.ptx_scene_get_instance_order.argtypes = [vp, vp]
     L.ptx_trace_closest.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint32]
     L.ptx_trace_any.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32]
+    L.ptx_trace_closest_stats.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32]
+    L.ptx_selftest_division.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.ptx_render_tiles.argtypes = [vp, C.POINTER(abi.PtxCamera), vp, C.c_uint32, C.c_uint64, vp, vp, C.c_uint32]
     L.ptx_make_tiles.restype = C.c_uint32
     L.ptx_make_tiles.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32]
@@ -181,6 +183,14 @@ class Scene:
         n = n if n is not None else rays.numel() * rays.element_size() // 32
         check(lib().ptx_trace_closest(self.h, rays.data_ptr(), n, hits.data_ptr(), _addr(bary)[0], _addr(inst)[0], flags | abi.PTX_MEM_DEVICE))
 
+    def trace_closest_stats(self, rays, flags=0):
+        """Per ray: interior nodes fetched, leaves entered, triangles tested."""
+        rays = np.ascontiguousarray(rays)
+        assert rays.dtype == abi.RAY_DTYPE
+        out = np.zeros((len(rays), 3), dtype=np.uint32)
+        check(lib().ptx_trace_closest_stats(self.h, rays.ctypes.data, len(rays), out.ctypes.data, flags))
+        return out
+
     def trace_any(self, rays, flags=0):
         rays = np.ascontiguousarray(rays)
         assert rays.dtype == abi.RAY_DTYPE
@@ -208,6 +218,13 @@ class Scene:
         c = abi.PtxCounters()
         check(lib().ptx_get_counters(self.h, C.byref(c)))
         return c
+
+
+def selftest_division(pairs, seed=1, device=0):
+    """Number of operand pairs (of `pairs`) on which the short division form differs from IEEE `/`."""
+    bad = C.c_uint64()
+    check(lib().ptx_selftest_division(device, pairs, seed, C.byref(bad)))
+    return bad.value
 
 
 def make_tiles(w, h, samples, fixed_seed):

@@ -18,7 +18,7 @@ constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_NOCULL = 0x40000000u;
 constexpr uint32_t REF_INDEX_MASK = 0x3FFFFFFFu;
 constexpr uint32_t MAX_LEAF_PRIMS = 15u;
-constexpr uint32_t MAX_LEAF_START = (1u << 26) - 1u;
+constexpr uint32_t MAX_LEAF_START = (1u << 26) - 2u;   // keeps 0xFFFFFFFF free as the traversal's end marker
 inline constexpr uint32_t make_leaf_ref(uint32_t start, uint32_t count) { return REF_LEAF | (start << 4) | count; }
 
 // Interior node of a binary tree: the boxes of both children and where they lead.
@@ -57,7 +57,7 @@ struct MeshRec {
 	uint32_t tri_base;      // first triangle of this mesh in the scene-wide triangle arrays
 	uint32_t n_tris;
 	uint32_t is_list;       // List<Triangle>: no box test, fold over all n_tris (list.h:25-32)
-	uint32_t pad;
+	uint32_t tame;          // every box coordinate is 0 or in [2^-70, 2^39): the short division form is exact
 };
 
 // One PT::Instance (instance.h:15-40).  Matrices column-major, element [col*4+row].
@@ -83,6 +83,8 @@ struct SceneRec {
 	uint32_t n_insts;
 	uint32_t top_is_list;     // List<Instance> (--no_bvh)
 	uint32_t mesh_only;       // queries go straight to meshes[0] (PT::Tri_Mesh::hit)
+	uint32_t top_tame;        // as MeshRec::tame, for the top-level tree
+	uint32_t top_stack_slots; // stack slots reserved for the top-level traversal
 	uint32_t pad;
 };
 

@@ -11,6 +11,7 @@
 
 #include "host_math.h"
 #include "scene.h"
+#include "persistent.hip.h"
 #include "traverse.hip.h"
 
 namespace ptx {
@@ -28,7 +29,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 // ------------------------------------------------------------------ kernels
-template<int MODE>
+template<int MODE, bool MESH_ONLY>
 __global__ void __launch_bounds__(256) k_trace_closest(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, PtxHit* __restrict__ hits,
                                                        float* __restrict__ bary, uint32_t* __restrict__ inst) {
 	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -38,7 +39,7 @@ __global__ void __launch_bounds__(256) k_trace_closest(SceneRec sc, const PtxRay
 	Ray3 r{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 	Stack st;
 	SceneHit h;
-	traverse_scene<MODE, false>(sc, r, st, h);
+	traverse_scene<MODE, false, false, MESH_ONLY>(sc, r, st, h);
 	PtxHit out;
 	out.distance = h.distance;
 	out.prim = h.hit ? h.prim : PTX_NO_HIT;
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(256) k_trace_closest(SceneRec sc, const PtxRay
 	if (inst) inst[i] = h.hit ? h.inst : PTX_NO_HIT;
 }
 
-template<int MODE>
+template<int MODE, bool MESH_ONLY>
 __global__ void __launch_bounds__(256) k_trace_any(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, uint8_t* __restrict__ occluded) {
 	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -56,8 +57,58 @@ __global__ void __launch_bounds__(256) k_trace_any(SceneRec sc, const PtxRay* __
 	Ray3 r{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 	Stack st;
 	SceneHit h;
-	traverse_scene<MODE, true>(sc, r, st, h);
+	traverse_scene<MODE, true, false, MESH_ONLY>(sc, r, st, h);
 	occluded[i] = h.hit ? 1 : 0;
+}
+
+// Diagnostic twin of k_trace_closest: per ray, the interior nodes fetched, leaves entered and
+// triangles tested.
+template<int MODE>
+__global__ void __launch_bounds__(256) k_trace_stats(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, uint32_t* __restrict__ stats3) {
+	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float4* rp = reinterpret_cast<const float4*>(rays + i);
+	const float4 a = rp[0], b = rp[1];
+	Ray3 r{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	Stack st;
+	SceneHit h;
+	TraverseStats ts{0, 0, 0};
+	traverse_scene<MODE, false, true>(sc, r, st, h, &ts);
+	stats3[i * 3 + 0] = ts.nodes, stats3[i * 3 + 1] = ts.leaves, stats3[i * 3 + 2] = ts.tris;
+}
+
+// Self test of the short division form: counts operand pairs for which div_by() differs in
+// any bit from the IEEE quotient.  Operands are drawn by a counter-based generator over the
+// range the traversal's static checks admit (numerator 0 or 2^-94..2^40, divisor 2^-40..2^10).
+__global__ void __launch_bounds__(256) k_selftest_division(uint64_t pairs_per_thread, uint64_t seed, unsigned long long* __restrict__ mismatches) {
+	uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x + 1));
+	auto next = [&]() {
+		x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+		return x;
+	};
+	unsigned long long bad = 0;
+	for (uint64_t k = 0; k < pairs_per_thread; k++) {
+		const uint64_t u = next(), w = next();
+		// divisor: sign, exponent in [-40, 10], random mantissa (every 16th: all-ones or all-zero mantissa)
+		uint32_t mb = uint32_t(u) & 0x7FFFFFu;
+		if ((u >> 60) == 0) mb = (u >> 59) & 1 ? 0x7FFFFFu : 0u;
+		const uint32_t eb = 127 - 40 + uint32_t((u >> 23) % 51);
+		const float b = __uint_as_float((uint32_t(u >> 32) & 0x80000000u) | (eb << 23) | mb);
+		// numerator: sign, exponent in [-94, 39], random mantissa; every 64th is an exact zero
+		uint32_t ma = uint32_t(w) & 0x7FFFFFu;
+		if ((w >> 60) == 1) ma = (w >> 59) & 1 ? 0x7FFFFFu : 0u;
+		const uint32_t ea = 127 - 94 + uint32_t((w >> 23) % 134);
+		float a = __uint_as_float((uint32_t(w >> 32) & 0x80000000u) | (ea << 23) | ma);
+		if ((w >> 58) == 3) a = 0.0f;
+		// every 8th pair: numerator near a multiple of the divisor (quotients close to rounding boundaries)
+		if (((u >> 55) & 7) == 0) a = b * float(int((w >> 40) & 0xFFFF) - 32768) * (1.0f + float(int(w & 7) - 3) * 5.9604645e-8f);
+		if (!(a == 0.0f || exp_within(a, -94, 39))) continue;
+		const float want = a / b;
+		const float got = div_by(a, b, refined_rcp(b));
+		// the traversal only compares quotients, so +0 and -0 are the same answer
+		if (__float_as_uint(want) != __float_as_uint(got) && !(want == 0.0f && got == 0.0f)) bad++;
+	}
+	if (bad) atomicAdd(mismatches, bad);
 }
 
 // ------------------------------------------------------------------ flattening
@@ -66,7 +117,17 @@ struct FlatTree {
 	uint32_t root_ref = make_leaf_ref(0, 0);
 	uint32_t depth = 0;
 	uint32_t n_nocull = 0;   // child references marked REF_NOCULL
+	bool tame = true;        // every stored box coordinate is 0 or in [2^-70, 2^39)
 };
+
+// Host twin of tame_coord() in traverse.hip.h.
+static bool tame_coord_host(float c) {
+	if (c == 0.0f) return true;
+	uint32_t bits;
+	std::memcpy(&bits, &c, 4);
+	const uint32_t e = (bits >> 23) & 0xFFu;
+	return e >= uint32_t(127 - 70) && e <= uint32_t(127 + 38);
+}
 
 // Canonical node array -> interior-only Node2 array (children's boxes pulled up into the
 // parent) numbered in depth-first order, leaves folded into child references.
@@ -117,6 +178,7 @@ static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_pr
 		return true;
 	};
 	const char* too_big = "a leaf holds more than 15 primitives (or starts beyond 2^26): not representable in the GPU layout";
+	for (int k = 0; k < 3; k++) out.tame = out.tame && tame_coord_host(nodes[0].bmin[k]) && tame_coord_host(nodes[0].bmax[k]);
 	if (nodes[0].l == nodes[0].r) {
 		if (!leaf_ref(0, out.root_ref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
 		return PTX_OK;
@@ -139,6 +201,14 @@ static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_pr
 		const PtxBvhNode &n = nodes[i], &l = nodes[n.l], &r = nodes[n.r];
 		Node2& d = out.nodes[interior_of[i]];
 		for (int k = 0; k < 3; k++) d.lmin[k] = l.bmin[k], d.lmax[k] = l.bmax[k], d.rmin[k] = r.bmin[k], d.rmax[k] = r.bmax[k];
+		// An empty leaf (the reference's "no split separates the primitives" case, bvh.cpp:183-221)
+		// carries an inverted FLT_MAX box; whether a ray "hits" it changes nothing, so store zeros.
+		if (l.l == l.r && l.size == 0)
+			for (int k = 0; k < 3; k++) d.lmin[k] = d.lmax[k] = 0.0f;
+		if (r.l == r.r && r.size == 0)
+			for (int k = 0; k < 3; k++) d.rmin[k] = d.rmax[k] = 0.0f;
+		for (int k = 0; k < 3; k++)
+			out.tame = out.tame && tame_coord_host(d.lmin[k]) && tame_coord_host(d.lmax[k]) && tame_coord_host(d.rmin[k]) && tame_coord_host(d.rmax[k]);
 		if (l.l == l.r) {
 			if (!leaf_ref(n.l, d.lref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
 		} else d.lref = interior_of[n.l] | (sticks_out[n.l] ? REF_NOCULL : 0u);
@@ -209,6 +279,7 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 		if (int rc = flatten_tree(bvh.nodes.data(), uint32_t(bvh.nodes.size()), m.n_tris, ordered.data(), ft)) return rc;
 		bvh.max_depth = ft.depth;
 		rec.root_ref = ft.root_ref;
+		rec.tame = ft.tame ? 1 : 0;
 		for (int k = 0; k < 3; k++) rec.root_min[k] = bvh.nodes[0].bmin[k], rec.root_max[k] = bvh.nodes[0].bmax[k];
 		sb.nodes.insert(sb.nodes.end(), ft.nodes.begin(), ft.nodes.end());
 		// BVH::bbox (bvh.cpp:433-436)
@@ -263,6 +334,9 @@ static int open_device(int device, PtxScene** out) {
 	PTX_HIP(hipSetDevice(device));
 	*out = new PtxScene();
 	(*out)->device = device;
+	int cus = 0;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+	(*out)->cu_count = uint32_t(cus);
 	return PTX_OK;
 }
 
@@ -276,6 +350,26 @@ static void free_scene(PtxScene* s) {
 }
 
 static void mat_copy(float* dst, const float* src) { std::memcpy(dst, src, 16 * sizeof(float)); }
+
+// Single-mesh scenes whose tree is tame run on the persistent kernel (persistent.hip.h).
+static bool use_persistent(const PtxScene* s) { return s->rec.mesh_only && s->persistent_ok; }
+
+template<bool ANY>
+static int launch_persistent(PtxScene* s, bool culled, const PtxRay* d_rays, uint64_t n, PtxHit* d_hits, float* d_bary, uint32_t* d_inst, uint8_t* d_occ) {
+	if (!s->next_ray) {
+		void* p = nullptr;
+		PTX_HIP(hipMalloc(&p, 256));
+		s->allocations.push_back(p);
+		s->next_ray = static_cast<unsigned long long*>(p);
+	}
+	PTX_HIP(hipMemsetAsync(s->next_ray, 0, 256, s->stream));
+	// enough 256-thread blocks to fill every CU at 8 waves per SIMD; each wave pulls rays until the pool is dry
+	const uint64_t want = (n + 255) / 256;
+	const dim3 block(256), grid(uint32_t(std::min<uint64_t>(want, uint64_t(s->cu_count) * 8)));
+	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray);
+	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray);
+	return PTX_OK;
+}
 
 }  // namespace ptx
 
@@ -341,6 +435,7 @@ int ptx_scene_create_mesh(int device, const PtxMeshDesc* mesh, ptx_scene_t* out)
 	if (!rc) rc = finish_geometry(s, sb);
 	if (!rc) {
 		s->rec.mesh_only = 1;
+		s->persistent_ok = !sb.meshes[0].is_list && sb.meshes[0].tame;
 		s->stack_need = s->mesh_bvhs[0].max_depth + 2;
 		if (s->stack_need > uint32_t(STACK_CAP)) rc = fail(PTX_ERR_UNSUPPORTED, "tree deeper than the traversal stack (64 entries)");
 	}
@@ -459,6 +554,8 @@ int ptx_scene_create(int device, const PtxSceneDesc* d, ptx_scene_t* out) {
 		if (int rc = flatten_tree(s->top_bvh.nodes.data(), uint32_t(s->top_bvh.nodes.size()), d->n_instances, ordered.data(), ft)) return bail(rc);
 		s->top_bvh.max_depth = ft.depth;
 		s->rec.top_ref = ft.root_ref;
+		s->rec.top_tame = ft.tame ? 1 : 0;
+		s->rec.top_stack_slots = ft.depth + 1;
 		s->rec.top_node_base = uint32_t(sb.nodes.size());
 		for (int k = 0; k < 3; k++) s->rec.top_min[k] = s->top_bvh.nodes[0].bmin[k], s->rec.top_max[k] = s->top_bvh.nodes[0].bmax[k];
 		sb.nodes.insert(sb.nodes.end(), ft.nodes.begin(), ft.nodes.end());
@@ -552,10 +649,16 @@ int ptx_trace_closest(ptx_scene_t s, const PtxRay* rays, uint64_t n, PtxHit* hit
 		d_inst = inst ? static_cast<uint32_t*>(s->scratch[3]) : nullptr;
 	}
 	const dim3 block(256), grid(uint32_t((n + 255) / 256));
-	if ((flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED)
-		hipLaunchKernelGGL(k_trace_closest<MODE_CULLED>, grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
-	else
-		hipLaunchKernelGGL(k_trace_closest<MODE_REFERENCE>, grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
+	const bool culled = (flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED;
+	if (use_persistent(s) && !(flags & PTX_NO_PERSISTENT)) {
+		if (int rc = launch_persistent<false>(s, culled, d_rays, n, d_hits, d_bary, d_inst, nullptr)) return rc;
+	} else if (s->rec.mesh_only) {
+		if (culled) hipLaunchKernelGGL((k_trace_closest<MODE_CULLED, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
+		else hipLaunchKernelGGL((k_trace_closest<MODE_REFERENCE, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
+	} else {
+		if (culled) hipLaunchKernelGGL((k_trace_closest<MODE_CULLED, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
+		else hipLaunchKernelGGL((k_trace_closest<MODE_REFERENCE, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
+	}
 	PTX_HIP(hipGetLastError());
 	s->counters.rays_closest += n;
 	if (host) {
@@ -584,14 +687,65 @@ int ptx_trace_any(ptx_scene_t s, const PtxRay* rays, uint64_t n, uint8_t* occlud
 		d_occ = static_cast<uint8_t*>(s->scratch[1]);
 	}
 	const dim3 block(256), grid(uint32_t((n + 255) / 256));
-	if ((flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED)
-		hipLaunchKernelGGL(k_trace_any<MODE_CULLED>, grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
-	else
-		hipLaunchKernelGGL(k_trace_any<MODE_REFERENCE>, grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
+	const bool culled = (flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED;
+	if (use_persistent(s) && !(flags & PTX_NO_PERSISTENT)) {
+		if (int rc = launch_persistent<true>(s, culled, d_rays, n, nullptr, nullptr, nullptr, d_occ)) return rc;
+	} else if (s->rec.mesh_only) {
+		if (culled) hipLaunchKernelGGL((k_trace_any<MODE_CULLED, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
+		else hipLaunchKernelGGL((k_trace_any<MODE_REFERENCE, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
+	} else {
+		if (culled) hipLaunchKernelGGL((k_trace_any<MODE_CULLED, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
+		else hipLaunchKernelGGL((k_trace_any<MODE_REFERENCE, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
+	}
 	PTX_HIP(hipGetLastError());
 	s->counters.rays_any += n;
 	if (host) PTX_HIP(hipMemcpyAsync(occluded, d_occ, n, hipMemcpyDeviceToHost, s->stream));
 	if (!(flags & PTX_ASYNC)) PTX_HIP(hipStreamSynchronize(s->stream));
+	return PTX_OK;
+}
+
+int ptx_trace_closest_stats(ptx_scene_t s, const PtxRay* rays, uint64_t n, uint32_t* stats3, uint32_t flags) {
+	if (!s || (n && (!rays || !stats3))) return fail(PTX_ERR_INVALID, "ptx_trace_closest_stats: null argument");
+	if (n == 0) return PTX_OK;
+	PTX_HIP(hipSetDevice(s->device));
+	const PtxRay* d_rays = rays;
+	uint32_t* d_stats = stats3;
+	const bool host = !(flags & PTX_MEM_DEVICE);
+	if (host) {
+		if (int rc = ensure_scratch(s, 0, n * sizeof(PtxRay))) return rc;
+		if (int rc = ensure_scratch(s, 1, n * 3 * sizeof(uint32_t))) return rc;
+		PTX_HIP(hipMemcpyAsync(s->scratch[0], rays, n * sizeof(PtxRay), hipMemcpyHostToDevice, s->stream));
+		d_rays = static_cast<const PtxRay*>(s->scratch[0]);
+		d_stats = static_cast<uint32_t*>(s->scratch[1]);
+	}
+	const dim3 block(256), grid(uint32_t((n + 255) / 256));
+	if ((flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED) hipLaunchKernelGGL(k_trace_stats<MODE_CULLED>, grid, block, 0, s->stream, s->rec, d_rays, n, d_stats);
+	else hipLaunchKernelGGL(k_trace_stats<MODE_REFERENCE>, grid, block, 0, s->stream, s->rec, d_rays, n, d_stats);
+	PTX_HIP(hipGetLastError());
+	if (host) PTX_HIP(hipMemcpyAsync(stats3, d_stats, n * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+	PTX_HIP(hipStreamSynchronize(s->stream));
+	return PTX_OK;
+}
+
+int ptx_selftest_division(int device, uint64_t pairs, uint64_t seed, uint64_t* mismatches) {
+	if (!mismatches) return fail(PTX_ERR_INVALID, "ptx_selftest_division: null argument");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(PTX_ERR_NO_DEVICE, "device index out of range");
+	PTX_HIP(hipSetDevice(device));
+	unsigned long long* d = nullptr;
+	PTX_HIP(hipMalloc(&d, sizeof(*d)));
+	hipError_t e = hipMemset(d, 0, sizeof(*d));
+	const uint32_t threads = 256 * 2048;
+	const uint64_t per_thread = (pairs + threads - 1) / threads;
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_selftest_division, dim3(2048), dim3(256), 0, nullptr, per_thread, seed, d);
+		e = hipGetLastError();
+	}
+	unsigned long long h = 0;
+	if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return hip_fail(e, "ptx_selftest_division");
+	*mismatches = h;
 	return PTX_OK;
 }
 

@@ -68,6 +68,9 @@ struct PtxScene {
 	std::vector<ptx::HostBvh> mesh_bvhs;
 	ptx::HostBvh top_bvh;
 	uint32_t stack_need = 0;        // deepest stack a traversal of this scene can need
+	uint32_t cu_count = 256;
+	bool persistent_ok = false;     // single tame BVH mesh: the replenishing kernel applies
+	unsigned long long* next_ray = nullptr;   // device counter of the replenishing kernel
 	uint64_t bytes_nodes = 0, bytes_tris = 0;
 	PtxCounters counters{};
 	// Scratch grown on demand (host-pointer calls, render state).

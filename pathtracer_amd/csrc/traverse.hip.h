@@ -1,9 +1,22 @@
 // traverse.hip.h -- gfx950 device code for ray queries against the flattened scene.
 //
 // Arithmetic contract: every value that decides a result is computed with the reference's
-// operations in the reference's order, in IEEE binary32 with true division and sqrt, no
-// fused multiply-add (this file must be compiled with -ffp-contract=off and without any
-// fast-math option) and subnormals kept.  The comments cite the reference lines restated.
+// operations in the reference's order, in IEEE binary32 with correctly rounded division and
+// sqrt, no fused multiply-add where the reference has a multiply and an add (this file must
+// be compiled with -ffp-contract=off and without any fast-math option) and subnormals kept.
+// The comments cite the reference lines restated.
+//
+// Division.  BBox::hit divides six times per box (bbox.h:110-120).  hipcc expands an IEEE
+// f32 division into v_div_scale x2, v_rcp, six fma/mul, v_div_fmas and v_div_fixup.  All
+// six divisions of a box test share one of three divisors (the ray direction), so the
+// divisor-only part of that expansion (v_rcp + two fma) is done once per ray, and each
+// quotient then costs the numerator-dependent part only: one multiply and four fma, the
+// very operations, in the order, of the compiler's expansion -- which is what makes the
+// quotient bit-identical to `a / b`.  The expansion's scaling and fix-up steps exist for
+// operands near the ends of the exponent range; the short form is used only when static
+// range checks on the ray and on the tree's coordinates prove they would be no-ops
+// (`FAST`), otherwise the plain `/` is used.  ptx_selftest_division compares the two forms
+// on the device.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -14,6 +27,7 @@ namespace ptx {
 constexpr int STACK_CAP = 64;            // traversal stack entries per lane
 constexpr float CULL_SCALE = 1.0001f;    // guard band of the culled modes (see ptx.h)
 constexpr float CULL_BIAS = 1e-7f;
+constexpr uint32_t REF_DONE = 0xFFFFFFFFu;   // leaf-shaped sentinel (no real leaf has both flag bits, start 2^26-1 and count 15)
 
 enum TraverseMode { MODE_REFERENCE = 0, MODE_CULLED = 1 };
 
@@ -29,20 +43,73 @@ struct MeshHit {
 	float u, v;
 };
 
+struct TraverseStats {
+	uint32_t nodes;   // interior nodes fetched (two box tests each)
+	uint32_t leaves;  // leaves entered
+	uint32_t tris;    // triangle tests
+};
+
 __device__ __forceinline__ float norm3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }  // vec3.h:155-160
+
+// ---- division -----------------------------------------------------------------------------
+// The divisor-only half of the f32 division expansion: v_rcp_f32 refined by one Newton step.
+__device__ __forceinline__ float refined_rcp(float b) {
+	const float r = __builtin_amdgcn_rcpf(b);
+	const float e = fmaf(-b, r, 1.0f);
+	return fmaf(e, r, r);
+}
+// The numerator-dependent half: a / b given y = refined_rcp(b).  Equal to the IEEE quotient
+// when no scaling or fix-up would have been needed (see ray_in_fast_range below).
+__device__ __forceinline__ float div_by(float a, float b, float y) {
+	float q = a * y;
+	float r = fmaf(-b, q, a);
+	q = fmaf(r, y, q);
+	r = fmaf(-b, q, a);
+	return fmaf(r, y, q);
+}
+// |x| in [2^lo, 2^hi] (x finite, normal), decided on the exponent field.
+__device__ __forceinline__ bool exp_within(float x, int lo, int hi) {
+	const uint32_t e = (__float_as_uint(x) >> 23) & 0xFFu;
+	return e >= uint32_t(127 + lo) && e <= uint32_t(127 + hi);
+}
+// A coordinate is "tame" when it is 0 or 2^-70 <= |c| < 2^39: the difference of two tame
+// coordinates is then 0 or at least 2^-94 and at most 2^40 in magnitude.
+__device__ __forceinline__ bool tame_coord(float c) { return c == 0.0f || exp_within(c, -70, 38); }
+// Ray-side half of the range proof: direction components in [2^-40, 2^11) and tame origin.
+// With a tame tree (MeshRec::tame / SceneRec::top_tame) every numerator (plane - origin) is
+// 0 or in [2^-94, 2^40], every quotient and every intermediate of div_by is a normal number
+// (or an exact zero), and the remainders are exactly representable: the division expansion's
+// v_div_scale would not scale and v_div_fixup would not alter the result.
+__device__ __forceinline__ bool ray_in_fast_range(const Ray3& r) {
+	return exp_within(r.dx, -40, 10) && exp_within(r.dy, -40, 10) && exp_within(r.dz, -40, 10) && tame_coord(r.ox) && tame_coord(r.oy) &&
+	       tame_coord(r.oz);
+}
+
+struct RayInv {
+	float yx, yy, yz;   // refined reciprocals of the direction (FAST only)
+};
 
 // BBox::hit(ray, times = (0, inf)) -- lib/bbox.h:81-154.  Returns the accept/reject decision;
 // `tnear` receives min_intersect (bbox.h:137), used only to order and cull in CULLED mode.
+template<bool FAST>
 __device__ __forceinline__ bool slab_test(float minx, float miny, float minz, float maxx, float maxy, float maxz, const Ray3& r,
-                                          float& tnear) {
-	if (r.dx == 0.0f && (r.ox < minx || r.ox > maxx)) return false;   // bbox.h:98-106
-	if (r.dy == 0.0f && (r.oy < miny || r.oy > maxy)) return false;
-	if (r.dz == 0.0f && (r.oz < minz || r.oz > maxz)) return false;
-	float tx0 = (minx - r.ox) / r.dx, tx1 = (maxx - r.ox) / r.dx;     // bbox.h:110-120
+                                          const RayInv& inv, float& tnear) {
+	float tx0, tx1, ty0, ty1, tz0, tz1;
+	if (FAST) {
+		// direction components are non-zero here, so the dir == 0 rejects (bbox.h:98-106) cannot fire
+		tx0 = div_by(minx - r.ox, r.dx, inv.yx), tx1 = div_by(maxx - r.ox, r.dx, inv.yx);
+		ty0 = div_by(miny - r.oy, r.dy, inv.yy), ty1 = div_by(maxy - r.oy, r.dy, inv.yy);
+		tz0 = div_by(minz - r.oz, r.dz, inv.yz), tz1 = div_by(maxz - r.oz, r.dz, inv.yz);
+	} else {
+		if (r.dx == 0.0f && (r.ox < minx || r.ox > maxx)) return false;   // bbox.h:98-106
+		if (r.dy == 0.0f && (r.oy < miny || r.oy > maxy)) return false;
+		if (r.dz == 0.0f && (r.oz < minz || r.oz > maxz)) return false;
+		tx0 = (minx - r.ox) / r.dx, tx1 = (maxx - r.ox) / r.dx;           // bbox.h:110-120
+		ty0 = (miny - r.oy) / r.dy, ty1 = (maxy - r.oy) / r.dy;
+		tz0 = (minz - r.oz) / r.dz, tz1 = (maxz - r.oz) / r.dz;
+	}
 	if (tx0 > tx1) { float s = tx0; tx0 = tx1; tx1 = s; }
-	float ty0 = (miny - r.oy) / r.dy, ty1 = (maxy - r.oy) / r.dy;
 	if (ty0 > ty1) { float s = ty0; ty0 = ty1; ty1 = s; }
-	float tz0 = (minz - r.oz) / r.dz, tz1 = (maxz - r.oz) / r.dz;
 	if (tz0 > tz1) { float s = tz0; tz0 = tz1; tz1 = s; }
 	if (tx0 > ty1 || tx1 < ty0) return false;                          // bbox.h:124
 	float lo = (tx0 > ty0) ? tx0 : ty0;                                // bbox.h:128-129
@@ -50,7 +117,7 @@ __device__ __forceinline__ bool slab_test(float minx, float miny, float minz, fl
 	if (lo > tz1 || hi < tz0) return false;                            // bbox.h:133
 	lo = (lo > tz0) ? lo : tz0;                                        // bbox.h:137-138
 	hi = (hi < tz1) ? hi : tz1;
-	if (lo > INFINITY || hi < 0.0f) return false;                      // bbox.h:142 with times = (0, inf)
+	if (hi < 0.0f) return false;                                       // bbox.h:142 with times = (0, inf): lo > inf is never true
 	tnear = lo;
 	return true;
 }
@@ -78,111 +145,154 @@ __device__ __forceinline__ bool triangle_test(const TriGeom* __restrict__ tris, 
 	return true;
 }
 
-// Trace::min(cur, candidate) for a candidate that hit -- trace.h:28-36: the candidate
-// replaces the running hit unless the running hit is strictly closer.
-__device__ __forceinline__ void merge_reference(MeshHit& cur, float d, float t, uint32_t prim, float u, float v) {
-	if (cur.hit && cur.distance < d) return;
-	cur.hit = true, cur.distance = d, cur.t = t, cur.prim = prim, cur.u = u, cur.v = v;
-}
-// Order-independent form of the same rule: closest distance, and among equal distances the
-// largest array position (what a left-to-right fold with the rule above ends with).
-__device__ __forceinline__ void merge_any_order(MeshHit& cur, float d, float t, uint32_t prim, float u, float v) {
-	if (cur.hit && !(d < cur.distance || (d == cur.distance && prim > cur.prim))) return;
-	cur.hit = true, cur.distance = d, cur.t = t, cur.prim = prim, cur.u = u, cur.v = v;
-}
-
 struct Stack {
 	uint32_t ref[STACK_CAP];
 	float tnear[STACK_CAP];
 };
 
-// PT::BVH<Triangle>::hit / hitRecursive (bvh.cpp:246-375) or List<Triangle>::hit
-// (list.h:25-32) for one mesh, with the stack slots from `base` upward.
-// ANY: stop at the first accepted triangle (occlusion query).
-template<int MODE, bool ANY>
-__device__ __forceinline__ void traverse_mesh(const SceneRec& sc, const MeshRec& mesh, const Ray3& r, Stack& st, int base, MeshHit& cur) {
-	const TriGeom* __restrict__ tris = sc.tris + mesh.tri_base;
-	const Node2* __restrict__ nodes = sc.nodes + mesh.node_base;
+// ---- traversal steps ------------------------------------------------------------------------
+// One traversal of PT::BVH<P>::hit / hitRecursive (bvh.cpp:246-375) over a flattened tree is a
+// sequence of these steps on the state (ref, sp):
+//   node_step  `ref` is an interior node: test both children's boxes, go to one, maybe push
+//              the other, or pop
+//   pop_ref    take the next pending subtree off the stack (or REF_DONE when none is left)
+// run_hit / run_dist are the caller's running Trace::hit and Trace::distance.
+//
+// REFERENCE: depth-first, left subtree completely before right (both entry times are 0 in
+// bvh.cpp:326-342); a sibling is skipped only when the running hit has a NaN distance
+// (bvh.cpp:337-339).  CULLED: nearer child first; a subtree whose entry distance lies beyond
+// the running closest distance (closest hit) or beyond dist_bounds.y (occlusion) by more
+// than the guard band is skipped, unless its reference is marked REF_NOCULL.
+template<bool ANY>
+__device__ __forceinline__ float cull_limit(const Ray3& r, bool run_hit, float run_dist) {
+	if (ANY) return r.tmax * CULL_SCALE + CULL_BIAS;
+	return run_hit ? run_dist * CULL_SCALE + CULL_BIAS : INFINITY;
+}
 
+template<int MODE, bool ANY>
+__device__ __forceinline__ void pop_ref(const Ray3& r, Stack& st, const int base, int& sp, uint32_t& ref, bool run_hit, float run_dist) {
+	for (;;) {
+		if (sp == base) {
+			ref = REF_DONE;
+			return;
+		}
+		--sp;
+		ref = st.ref[sp];
+		if (MODE == MODE_REFERENCE) {
+			if (run_hit && !(run_dist >= 0.0f)) continue;   // bvh.cpp:337-339
+			return;
+		} else {
+			if (!ANY && !(ref & REF_NOCULL) && st.tnear[sp] > cull_limit<ANY>(r, run_hit, run_dist)) continue;
+			return;
+		}
+	}
+}
+
+template<int MODE, bool ANY, bool FAST, bool STATS>
+__device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const Ray3& r, const RayInv& inv, Stack& st, const int base, int& sp,
+                                          uint32_t& ref, bool run_hit, float run_dist, TraverseStats* stats) {
+	const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
+	const float4 n0 = p[0], n1 = p[1], n2 = p[2];
+	const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
+	if (STATS) stats->nodes++;
+	float tl, tr;
+	const bool hl = slab_test<FAST>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl);
+	const bool hr = slab_test<FAST>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr);
+	if (MODE == MODE_REFERENCE) {
+		if (hl) {
+			if (hr) st.ref[sp++] = kids.y;
+			ref = kids.x;
+		} else if (hr && !(run_hit && !(run_dist >= 0.0f))) {
+			ref = kids.y;
+		} else {
+			pop_ref<MODE, ANY>(r, st, base, sp, ref, run_hit, run_dist);
+		}
+	} else {
+		const float limit = cull_limit<ANY>(r, run_hit, run_dist);
+		const bool gl = hl && ((kids.x & REF_NOCULL) || !(tl > limit)), gr = hr && ((kids.y & REF_NOCULL) || !(tr > limit));
+		if (gl && gr) {
+			const bool left_first = !(tr < tl);
+			st.ref[sp] = left_first ? kids.y : kids.x;
+			st.tnear[sp] = left_first ? tr : tl;
+			sp++;
+			ref = left_first ? kids.x : kids.y;
+		} else if (gl) {
+			ref = kids.x;
+		} else if (gr) {
+			ref = kids.y;
+		} else {
+			pop_ref<MODE, ANY>(r, st, base, sp, ref, run_hit, run_dist);
+		}
+	}
+}
+
+// A whole traversal: walk interior nodes until every lane of the wave holds a leaf (or is
+// finished), then intersect leaves -- two nested phases, so the box-test code and the
+// primitive-test code each run with as many lanes active as possible.
+//   leaf(first, count) -> bool   tests primitives [first, first+count) in array order, folds them
+//                                into the caller's running hit, returns true to stop (ANY mode)
+template<int MODE, bool ANY, bool FAST, bool STATS, typename Leaf>
+__device__ __forceinline__ void traverse_tree(const Node2* __restrict__ nodes, uint32_t root_ref, const Ray3& r, const RayInv& inv, Stack& st,
+                                              const int base, Leaf&& leaf, const bool& run_hit, const float& run_dist, TraverseStats* stats) {
+	int sp = base;
+	uint32_t ref = root_ref;
+	for (;;) {
+		while (!(ref & REF_LEAF)) node_step<MODE, ANY, FAST, STATS>(nodes, r, inv, st, base, sp, ref, run_hit, run_dist, stats);
+		if (ref == REF_DONE) return;
+		if (STATS) stats->leaves++;
+		if (leaf((ref & REF_INDEX_MASK) >> 4, ref & 15u)) return;
+		pop_ref<MODE, ANY>(r, st, base, sp, ref, run_hit, run_dist);
+	}
+}
+
+// Triangles [first, first+count) of a mesh folded into the running hit, in array order.
+template<int MODE, bool ANY, bool STATS>
+__device__ __forceinline__ bool mesh_leaf(const TriGeom* __restrict__ tris, uint32_t first, uint32_t count, const Ray3& r, MeshHit& cur,
+                                          TraverseStats* stats) {
+	for (uint32_t i = first; i < first + count; i++) {
+		float d, t, u, v;
+		if (STATS) stats->tris++;
+		if (triangle_test(tris, i, r, d, t, u, v)) {
+			// Trace::min(cur, candidate), trace.h:28-36: the candidate replaces the running hit unless
+			// the running hit is strictly closer.  In array order that leaves, among equal distances,
+			// the largest array position; the culled mode visits in another order and asks for that
+			// outcome explicitly.
+			const bool keep = MODE == MODE_REFERENCE ? (cur.hit && cur.distance < d)
+			                                         : (cur.hit && !(d < cur.distance || (d == cur.distance && i > cur.prim)));
+			if (!keep) cur.hit = true, cur.distance = d, cur.t = t, cur.prim = i, cur.u = u, cur.v = v;
+			if (ANY) return true;
+		} else if (!cur.hit) {
+			cur.distance = 0.0f;   // Trace::min of two misses is a default Trace (trace.h:35)
+		}
+	}
+	return false;
+}
+
+// PT::BVH<Triangle>::hit (bvh.cpp:246-270) or List<Triangle>::hit (list.h:25-32) for one mesh.
+template<int MODE, bool ANY, bool STATS>
+__device__ __forceinline__ void traverse_mesh(const SceneRec& sc, const MeshRec& mesh, const Ray3& r, Stack& st, int base, MeshHit& cur,
+                                              TraverseStats* stats) {
+	const TriGeom* __restrict__ tris = sc.tris + mesh.tri_base;
+	auto leaf = [&](uint32_t first, uint32_t count) -> bool { return mesh_leaf<MODE, ANY, STATS>(tris, first, count, r, cur, stats); };
 	if (mesh.is_list) {
 		// List::hit starts from a default Trace (hit = false, distance = 0) and never tests a box.
 		cur.hit = false, cur.distance = 0.0f, cur.prim = 0xFFFFFFFFu;
-		for (uint32_t i = 0; i < mesh.n_tris; i++) {
-			float d, t, u, v;
-			if (triangle_test(tris, i, r, d, t, u, v)) {
-				merge_reference(cur, d, t, i, u, v);
-				if (ANY) return;
-			}
-		}
+		for (uint32_t first = 0; first < mesh.n_tris; first += 8)
+			if (leaf(first, min(8u, mesh.n_tris - first))) return;
 		return;
 	}
-
 	// BVH::hit seeds the running Trace with hit = false, distance = inf (bvh.cpp:257-259).
 	cur.hit = false, cur.distance = INFINITY, cur.prim = 0xFFFFFFFFu;
+	const Node2* __restrict__ nodes = sc.nodes + mesh.node_base;
+	RayInv inv{};
 	float tn;
-	if (!slab_test(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], r, tn)) return;
-
-	int sp = base;
-	uint32_t ref = mesh.root_ref;
-	for (;;) {
-		if (ref & REF_LEAF) {
-			const uint32_t first = (ref & REF_INDEX_MASK) >> 4, count = ref & 15u;
-			for (uint32_t i = first; i < first + count; i++) {
-				float d, t, u, v;
-				if (triangle_test(tris, i, r, d, t, u, v)) {
-					if (MODE == MODE_REFERENCE) merge_reference(cur, d, t, i, u, v);
-					else merge_any_order(cur, d, t, i, u, v);
-					if (ANY) return;
-				} else if (!cur.hit) {
-					cur.distance = 0.0f;   // Trace::min of two misses is a default Trace (trace.h:35)
-				}
-			}
-		} else {
-			const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
-			const float4 n0 = p[0], n1 = p[1], n2 = p[2];
-			const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
-			float tl, tr;
-			const bool hl = slab_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, tl);
-			const bool hr = slab_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, tr);
-			if (MODE == MODE_REFERENCE) {
-				// Left subtree completely, then right (bvh.cpp:326-342: both entry times are 0).
-				if (hl) {
-					if (hr) st.ref[sp++] = kids.y;
-					ref = kids.x;
-					continue;
-				}
-				if (hr && !(cur.hit && !(cur.distance >= 0.0f))) {   // bvh.cpp:337-339 (NaN distance skips the sibling)
-					ref = kids.y;
-					continue;
-				}
-			} else {
-				const float limit = ANY ? r.tmax * CULL_SCALE + CULL_BIAS : (cur.hit ? cur.distance * CULL_SCALE + CULL_BIAS : INFINITY);
-				const bool gl = hl && ((kids.x & REF_NOCULL) || !(tl > limit)), gr = hr && ((kids.y & REF_NOCULL) || !(tr > limit));
-				if (gl && gr) {
-					const bool left_first = !(tr < tl);
-					st.ref[sp] = left_first ? kids.y : kids.x;
-					st.tnear[sp] = left_first ? tr : tl;
-					sp++;
-					ref = left_first ? kids.x : kids.y;
-					continue;
-				}
-				if (gl) { ref = kids.x; continue; }
-				if (gr) { ref = kids.y; continue; }
-			}
-		}
-		// pop
-		for (;;) {
-			if (sp == base) return;
-			--sp;
-			ref = st.ref[sp];
-			if (MODE == MODE_REFERENCE) {
-				if (cur.hit && !(cur.distance >= 0.0f)) continue;   // bvh.cpp:337-339
-				break;
-			} else {
-				if (!ANY && cur.hit && !(ref & REF_NOCULL) && st.tnear[sp] > cur.distance * CULL_SCALE + CULL_BIAS) continue;
-				break;
-			}
-		}
+	if (mesh.tame && ray_in_fast_range(r)) {
+		inv.yx = refined_rcp(r.dx), inv.yy = refined_rcp(r.dy), inv.yz = refined_rcp(r.dz);
+		if (!slab_test<true>(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], r, inv, tn)) return;
+		traverse_tree<MODE, ANY, true, STATS>(nodes, mesh.root_ref, r, inv, st, base, leaf, cur.hit, cur.distance, stats);
+	} else {
+		if (!slab_test<false>(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], r, inv, tn)) return;
+		traverse_tree<MODE, ANY, false, STATS>(nodes, mesh.root_ref, r, inv, st, base, leaf, cur.hit, cur.distance, stats);
 	}
 }
 
@@ -224,7 +334,7 @@ __device__ __forceinline__ bool sphere_test(float radius, const Ray3& r, float& 
 	const float t1 = (-2 * od + sq) / (2 * d2);
 	const float t2 = (-2 * od - sq) / (2 * d2);
 	const bool w1 = t1 >= r.tmin && t1 <= r.tmax, w2 = t2 >= r.tmin && t2 <= r.tmax;
-	if (w1 && w2) t_out = fminf(t1, t2);   // std::min(t1, t2): both are ordinary numbers here
+	if (w1 && w2) t_out = (t2 < t1) ? t2 : t1;   // std::min(t1, t2)
 	else if (w1) t_out = t1;
 	else if (w2) t_out = t2;
 	else return false;
@@ -240,8 +350,9 @@ struct SceneHit {
 
 // Instance::hit (pathtracer/instance.h:32-40): ray into object space, geometry hit, Trace
 // back to world space with distance recomputed from the transformed points (trace.h:38-43).
-template<int MODE, bool ANY>
-__device__ __forceinline__ bool instance_hit(const SceneRec& sc, uint32_t inst_index, const Ray3& world, Stack& st, int base, SceneHit& out) {
+template<int MODE, bool ANY, bool STATS>
+__device__ __forceinline__ bool instance_hit(const SceneRec& sc, uint32_t inst_index, const Ray3& world, Stack& st, int base, SceneHit& out,
+                                             TraverseStats* stats) {
 	const InstRec& in = sc.insts[inst_index];
 	Ray3 r = world;
 	if (in.has_transform) r = ray_transform(in.iT, world);
@@ -249,7 +360,7 @@ __device__ __forceinline__ bool instance_hit(const SceneRec& sc, uint32_t inst_i
 	uint32_t prim = 0;
 	if (in.mesh >= 0) {
 		MeshHit mh;
-		traverse_mesh<MODE, ANY>(sc, sc.meshes[in.mesh], r, st, base, mh);
+		traverse_mesh<MODE, ANY, STATS>(sc, sc.meshes[in.mesh], r, st, base, mh, stats);
 		if (!mh.hit) return false;
 		t = mh.t, dist = mh.distance, u = mh.u, v = mh.v, prim = mh.prim;
 	} else {
@@ -270,95 +381,50 @@ __device__ __forceinline__ bool instance_hit(const SceneRec& sc, uint32_t inst_i
 
 // Aggregate::hit over BVH<Instance> / List<Instance> (aggregate.h:41-43), or Tri_Mesh::hit
 // when the scene is a single mesh.
-template<int MODE, bool ANY>
-__device__ __forceinline__ void traverse_scene(const SceneRec& sc, const Ray3& r, Stack& st, SceneHit& cur) {
-	if (sc.mesh_only) {
+// MESH_ONLY is a compile-time promise that sc.mesh_only is set: the two-level code is then
+// not even compiled into the kernel, which keeps its register count (and so occupancy) down.
+template<int MODE, bool ANY, bool STATS = false, bool MESH_ONLY = false>
+__device__ __forceinline__ void traverse_scene(const SceneRec& sc, const Ray3& r, Stack& st, SceneHit& cur, TraverseStats* stats = nullptr) {
+	if (MESH_ONLY || sc.mesh_only) {
 		MeshHit mh;
-		traverse_mesh<MODE, ANY>(sc, sc.meshes[0], r, st, 0, mh);
+		traverse_mesh<MODE, ANY, STATS>(sc, sc.meshes[0], r, st, 0, mh, stats);
 		cur.hit = mh.hit, cur.distance = mh.distance, cur.prim = mh.prim, cur.inst = 0, cur.u = mh.u, cur.v = mh.v;
 		return;
 	}
-	auto merge = [&](const SceneHit& h) {
-		if (MODE == MODE_REFERENCE) {
-			if (cur.hit && cur.distance < h.distance) return;
-		} else {
-			if (cur.hit && !(h.distance < cur.distance || (h.distance == cur.distance && h.inst > cur.inst))) return;
+	if (MESH_ONLY) return;
+	// The top level owns the first top_stack_slots stack slots; instances use the rest.
+	const int inst_base = int(sc.top_stack_slots);
+	auto leaf = [&](uint32_t first, uint32_t count) -> bool {
+		for (uint32_t i = first; i < first + count; i++) {
+			SceneHit h;
+			if (instance_hit<MODE, ANY, STATS>(sc, i, r, st, inst_base, h, stats)) {
+				const bool keep = MODE == MODE_REFERENCE ? (cur.hit && cur.distance < h.distance)
+				                                         : (cur.hit && !(h.distance < cur.distance || (h.distance == cur.distance && h.inst > cur.inst)));
+				if (!keep) cur = h;
+				if (ANY) return true;
+			} else if (!cur.hit) {
+				cur.distance = 0.0f;
+			}
 		}
-		cur = h;
+		return false;
 	};
 	if (sc.top_is_list) {
 		cur.hit = false, cur.distance = 0.0f, cur.prim = 0xFFFFFFFFu, cur.inst = 0xFFFFFFFFu;
-		for (uint32_t i = 0; i < sc.n_insts; i++) {
-			SceneHit h;
-			if (instance_hit<MODE, ANY>(sc, i, r, st, 0, h)) {
-				merge(h);
-				if (ANY) return;
-			}
-		}
+		for (uint32_t i = 0; i < sc.n_insts; i++)
+			if (leaf(i, 1)) return;
 		return;
 	}
 	cur.hit = false, cur.distance = INFINITY, cur.prim = 0xFFFFFFFFu, cur.inst = 0xFFFFFFFFu;
-	float tn;
-	if (!slab_test(sc.top_min[0], sc.top_min[1], sc.top_min[2], sc.top_max[0], sc.top_max[1], sc.top_max[2], r, tn)) return;
 	const Node2* __restrict__ nodes = sc.nodes + sc.top_node_base;
-	int sp = 0;
-	uint32_t ref = sc.top_ref;
-	for (;;) {
-		if (ref & REF_LEAF) {
-			const uint32_t first = (ref & REF_INDEX_MASK) >> 4, count = ref & 15u;
-			for (uint32_t i = first; i < first + count; i++) {
-				SceneHit h;
-				if (instance_hit<MODE, ANY>(sc, i, r, st, sp, h)) {
-					merge(h);
-					if (ANY) return;
-				} else if (!cur.hit) {
-					cur.distance = 0.0f;
-				}
-			}
-		} else {
-			const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
-			const float4 n0 = p[0], n1 = p[1], n2 = p[2];
-			const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
-			float tl, tr;
-			const bool hl = slab_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, tl);
-			const bool hr = slab_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, tr);
-			if (MODE == MODE_REFERENCE) {
-				if (hl) {
-					if (hr) st.ref[sp++] = kids.y;
-					ref = kids.x;
-					continue;
-				}
-				if (hr && !(cur.hit && !(cur.distance >= 0.0f))) {
-					ref = kids.y;
-					continue;
-				}
-			} else {
-				const float limit = ANY ? r.tmax * CULL_SCALE + CULL_BIAS : (cur.hit ? cur.distance * CULL_SCALE + CULL_BIAS : INFINITY);
-				const bool gl = hl && ((kids.x & REF_NOCULL) || !(tl > limit)), gr = hr && ((kids.y & REF_NOCULL) || !(tr > limit));
-				if (gl && gr) {
-					const bool left_first = !(tr < tl);
-					st.ref[sp] = left_first ? kids.y : kids.x;
-					st.tnear[sp] = left_first ? tr : tl;
-					sp++;
-					ref = left_first ? kids.x : kids.y;
-					continue;
-				}
-				if (gl) { ref = kids.x; continue; }
-				if (gr) { ref = kids.y; continue; }
-			}
-		}
-		for (;;) {
-			if (sp == 0) return;
-			--sp;
-			ref = st.ref[sp];
-			if (MODE == MODE_REFERENCE) {
-				if (cur.hit && !(cur.distance >= 0.0f)) continue;
-				break;
-			} else {
-				if (!ANY && cur.hit && !(ref & REF_NOCULL) && st.tnear[sp] > cur.distance * CULL_SCALE + CULL_BIAS) continue;
-				break;
-			}
-		}
+	RayInv inv{};
+	float tn;
+	if (sc.top_tame && ray_in_fast_range(r)) {
+		inv.yx = refined_rcp(r.dx), inv.yy = refined_rcp(r.dy), inv.yz = refined_rcp(r.dz);
+		if (!slab_test<true>(sc.top_min[0], sc.top_min[1], sc.top_min[2], sc.top_max[0], sc.top_max[1], sc.top_max[2], r, inv, tn)) return;
+		traverse_tree<MODE, ANY, true, STATS>(nodes, sc.top_ref, r, inv, st, 0, leaf, cur.hit, cur.distance, stats);
+	} else {
+		if (!slab_test<false>(sc.top_min[0], sc.top_min[1], sc.top_min[2], sc.top_max[0], sc.top_max[1], sc.top_max[2], r, inv, tn)) return;
+		traverse_tree<MODE, ANY, false, STATS>(nodes, sc.top_ref, r, inv, st, 0, leaf, cur.hit, cur.distance, stats);
 	}
 }
 

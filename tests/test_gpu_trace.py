@@ -12,7 +12,8 @@ from pathtracer_amd import abi, capi, synth
 
 pytestmark = pytest.mark.gpu
 
-MODES = [abi.PTX_TRAVERSE_REFERENCE, abi.PTX_TRAVERSE_CULLED]
+MODES = [abi.PTX_TRAVERSE_REFERENCE, abi.PTX_TRAVERSE_CULLED,
+         abi.PTX_TRAVERSE_REFERENCE | abi.PTX_NO_PERSISTENT, abi.PTX_TRAVERSE_CULLED | abi.PTX_NO_PERSISTENT]
 
 
 def assert_same_hits(got, want, what):

@@ -58,7 +58,10 @@ enum {
 	PTX_TRAVERSE_MASK = 3u << 4,
 	/* Run the one-ray-per-lane kernel even where the replenishing kernel applies (A/B timing and
 	 * tests; results are identical). */
-	PTX_NO_PERSISTENT = 1u << 8
+	PTX_NO_PERSISTENT = 1u << 8,
+	/* The batch is already ordered so that neighbouring rays travel together (camera rays in
+	 * pixel order, ...): skip the library's own grouping pass (results are identical). */
+	PTX_RAYS_COHERENT = 1u << 9
 };
 
 /* ------------------------------------------------------------------ rays and hits */

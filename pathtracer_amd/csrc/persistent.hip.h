@@ -6,6 +6,9 @@
 // slots: whenever enough slots have run dry (a wave-wide __ballot), the wave takes that many
 // new rays from a global counter with ONE atomic (lane ranks by prefix popcount of the
 // ballot mask) and the dry lanes start over on the new rays while the others carry on.
+// A wave claims WAVE_CHUNK consecutive slots of the (grouped) ray order at a time and refills
+// from its own chunk, so the rays that share a wave at any moment are neighbours in that
+// order -- the coherence the grouping pass created survives the replenishment.
 // The arithmetic per ray is the same as in traverse_tree(); only the order in which rays are
 // picked up changes, and no result depends on that.
 #pragma once
@@ -14,26 +17,34 @@
 namespace ptx {
 
 constexpr int REFILL_MIN_IDLE = 20;   // refill when at least this many of the 64 slots are dry
+constexpr int PERSISTENT_LDS_SLOTS = 12;   // stack entries per lane kept in LDS (8 B each)
+constexpr unsigned long long WAVE_CHUNK = 256;    // consecutive ray slots a wave claims at a time
 
 template<int MODE, bool ANY>
 __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, PtxHit* __restrict__ hits,
                                                          float* __restrict__ bary, uint32_t* __restrict__ inst, uint8_t* __restrict__ occluded,
-                                                         unsigned long long* __restrict__ next_ray) {
+                                                         unsigned long long* __restrict__ next_ray, const int refill_min_idle,
+                                                         const uint32_t* __restrict__ order, uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count) {
 	const MeshRec mesh = sc.meshes[0];
 	const TriGeom* __restrict__ tris = sc.tris + mesh.tri_base;
 	const Node2* __restrict__ nodes = sc.nodes + mesh.node_base;
 	const unsigned lane = threadIdx.x & 63u;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-	Stack st;
+	__shared__ uint32_t lds_ref[PERSISTENT_LDS_SLOTS * 256];
+	__shared__ float lds_tnear[PERSISTENT_LDS_SLOTS * 256];
+	StackT<PERSISTENT_LDS_SLOTS> st;
+	st.lds_ref = lds_ref + threadIdx.x, st.lds_tnear = lds_tnear + threadIdx.x, st.stride = 256;
 	int sp = 0;
 	uint32_t ref = REF_DONE;          // REF_DONE + have_ray == false: the slot is dry
+	uint32_t tri_k = 0;               // next triangle of the leaf `ref` stands in
 	bool have_ray = false;
 	uint64_t ray_index = 0;
 	Ray3 r{};
 	RayInv inv{};
 	MeshHit cur{};
 	bool pool_empty = false;
+	unsigned long long chunk_next = 0, chunk_end = 0;   // this wave's claimed slots [chunk_next, chunk_end), wave-uniform
 
 	auto store_result = [&]() {
 		if (ANY) {
@@ -54,15 +65,22 @@ __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxR
 		const unsigned long long dry = __ballot(!have_ray);
 		const int n_dry = __popcll(dry);
 		if (n_dry == 64 && pool_empty) break;
-		if (!pool_empty && n_dry >= REFILL_MIN_IDLE) {
-			unsigned long long base = 0;
-			const unsigned leader = __ffsll((long long)dry) - 1;
-			if (lane == leader) base = atomicAdd(next_ray, (unsigned long long)n_dry);
-			base = __shfl(base, leader);
-			if (base + n_dry >= n) pool_empty = true;
+		if (!pool_empty && n_dry >= refill_min_idle) {
+			if (chunk_next >= chunk_end) {   // claim the next chunk (one atomic per WAVE_CHUNK rays)
+				unsigned long long base = 0;
+				if (lane == 0) base = atomicAdd(next_ray, WAVE_CHUNK);
+				base = __shfl(base, 0);
+				chunk_next = base, chunk_end = base + WAVE_CHUNK < n ? base + WAVE_CHUNK : n;
+				if (base >= n) chunk_next = chunk_end = n;
+			}
+			const unsigned long long base = chunk_next;
+			const unsigned long long take = (unsigned long long)n_dry < chunk_end - chunk_next ? (unsigned long long)n_dry : chunk_end - chunk_next;
+			chunk_next += take;
+			if (chunk_next >= n) pool_empty = true;
 			if (!have_ray) {
-				const uint64_t idx = base + __popcll(dry & lanes_below);
-				if (idx < n) {
+				const uint64_t slot = base + __popcll(dry & lanes_below);
+				if (slot < base + take) {
+					const uint64_t idx = order ? uint64_t(order[slot]) : slot;   // rays grouped for coherence (raysort.hip.h)
 					ray_index = idx;
 					have_ray = true;
 					const float4* rp = reinterpret_cast<const float4*>(rays + idx);
@@ -74,29 +92,74 @@ __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxR
 						inv.yx = refined_rcp(r.dx), inv.yy = refined_rcp(r.dy), inv.yz = refined_rcp(r.dz);
 						float tn;
 						sp = 0;
+						tri_k = 0;
 						if (slab_test<true>(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], r, inv, tn))
 							ref = mesh.root_ref;
 						else
 							ref = REF_DONE;
 					} else {
 						// Outside the range where the short division form is proven exact (a zero direction
-						// component, a huge or tiny coordinate): rare, so run the whole query now with `/`.
-						traverse_mesh<MODE, ANY, false>(sc, mesh, r, st, 0, cur, nullptr);
+						// component, a huge or tiny coordinate): rare.  Hand the ray to k_mesh_deferred, which
+						// runs the plain-division traversal, so that code stays out of this kernel.
+						slow_list[atomicAdd(slow_count, 1u)] = uint32_t(idx);
+						have_ray = false;
 						ref = REF_DONE;
 					}
 				}
 			}
 		}
-		// ---- traverse until too many slots are dry again (or, once the pool is empty, until all are)
-		for (;;) {
-			while (!(ref & REF_LEAF)) node_step<MODE, ANY, true, false>(nodes, r, inv, st, 0, sp, ref, cur.hit, cur.distance, nullptr);
-			if (ref != REF_DONE) {
-				if (mesh_leaf<MODE, ANY, false>(tris, (ref & REF_INDEX_MASK) >> 4, ref & 15u, r, cur, nullptr)) ref = REF_DONE;
-				else pop_ref<MODE, ANY>(r, st, 0, sp, ref, cur.hit, cur.distance);
+		// ---- one step for every busy slot: a box-test step for the lanes standing on an interior
+		// node, then one triangle for the lanes standing in a leaf.  The load/return path of the
+		// CU's vector memory pipeline is paid per wave instruction, however few lanes are active,
+		// so the step is shaped to advance as many lanes as possible per memory instruction.
+		if (__ballot(!(ref & REF_LEAF)) != 0ull) {
+			if (!(ref & REF_LEAF)) {
+				node_step<MODE, ANY, true, false>(nodes, r, inv, st, 0, sp, ref, cur.hit, cur.distance, nullptr);
+				tri_k = 0;
 			}
-			if (ref == REF_DONE && have_ray) store_result();
-			const int busy = __popcll(__ballot(have_ray));
-			if (busy == 0 || (!pool_empty && 64 - busy >= REFILL_MIN_IDLE)) break;
+		}
+		if (__ballot(ref != REF_DONE && (ref & REF_LEAF)) != 0ull) {
+			if (ref != REF_DONE && (ref & REF_LEAF)) {
+				const uint32_t first = (ref & REF_INDEX_MASK) >> 4, count = ref & 15u;
+				bool stop = false;
+				if (tri_k < count) {
+					stop = mesh_leaf<MODE, ANY, false>(tris, first + tri_k, 1, r, cur, nullptr);
+					tri_k++;
+				}
+				if (stop) ref = REF_DONE;
+				else if (tri_k >= count) {
+					pop_ref<MODE, ANY>(r, st, 0, sp, ref, cur.hit, cur.distance);
+					tri_k = 0;
+				}
+			}
+		}
+		if (ref == REF_DONE && have_ray) store_result();
+	}
+}
+
+// The rays k_mesh_persistent set aside: one ray per lane, plain `/` divisions.
+template<int MODE, bool ANY>
+__global__ void __launch_bounds__(256) k_mesh_deferred(SceneRec sc, const PtxRay* __restrict__ rays, const uint32_t* __restrict__ list,
+                                                       const uint32_t* __restrict__ count, PtxHit* __restrict__ hits, float* __restrict__ bary,
+                                                       uint32_t* __restrict__ inst, uint8_t* __restrict__ occluded) {
+	const uint32_t n = *count;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const uint32_t i = list[k];
+		const float4* rp = reinterpret_cast<const float4*>(rays + i);
+		const float4 a = rp[0], b = rp[1];
+		Ray3 r{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+		Stack st;
+		MeshHit cur;
+		traverse_mesh<MODE, ANY, false>(sc, sc.meshes[0], r, st, 0, cur, nullptr);
+		if (ANY) {
+			occluded[i] = cur.hit ? 1 : 0;
+		} else {
+			PtxHit out;
+			out.distance = cur.distance;
+			out.prim = cur.hit ? cur.prim : PTX_NO_HIT;
+			hits[i] = out;
+			if (bary) reinterpret_cast<float2*>(bary)[i] = cur.hit ? make_float2(cur.u, cur.v) : make_float2(0.0f, 0.0f);
+			if (inst) inst[i] = cur.hit ? 0u : PTX_NO_HIT;
 		}
 	}
 }

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -12,6 +13,7 @@
 #include "host_math.h"
 #include "scene.h"
 #include "persistent.hip.h"
+#include "raysort.hip.h"
 #include "traverse.hip.h"
 
 namespace ptx {
@@ -72,9 +74,9 @@ __global__ void __launch_bounds__(256) k_trace_stats(SceneRec sc, const PtxRay* 
 	Ray3 r{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 	Stack st;
 	SceneHit h;
-	TraverseStats ts{0, 0, 0};
+	TraverseStats ts{0, 0, 0, 0};
 	traverse_scene<MODE, false, true>(sc, r, st, h, &ts);
-	stats3[i * 3 + 0] = ts.nodes, stats3[i * 3 + 1] = ts.leaves, stats3[i * 3 + 2] = ts.tris;
+	stats3[i * 3 + 0] = ts.nodes | (ts.max_sp << 24), stats3[i * 3 + 1] = ts.leaves, stats3[i * 3 + 2] = ts.tris;
 }
 
 // Self test of the short division form: counts operand pairs for which div_by() differs in
@@ -354,8 +356,44 @@ static void mat_copy(float* dst, const float* src) { std::memcpy(dst, src, 16 * 
 // Single-mesh scenes whose tree is tame run on the persistent kernel (persistent.hip.h).
 static bool use_persistent(const PtxScene* s) { return s->rec.mesh_only && s->persistent_ok; }
 
+static int grow_scratch(PtxScene* s, int slot, size_t bytes) {
+	if (s->scratch_bytes[slot] >= bytes) return PTX_OK;
+	if (s->scratch[slot]) PTX_HIP(hipFree(s->scratch[slot]));
+	s->scratch[slot] = nullptr, s->scratch_bytes[slot] = 0;
+	PTX_HIP(hipMalloc(&s->scratch[slot], bytes));
+	s->scratch_bytes[slot] = bytes;
+	return PTX_OK;
+}
+
+// Groups the batch by origin cell and direction octant (raysort.hip.h); *order receives the
+// device array of ray indices in that order.
+static int sort_rays(PtxScene* s, const PtxRay* d_rays, uint64_t n, const uint32_t** order) {
+	if (int rc = grow_scratch(s, 4, n * sizeof(uint32_t))) return rc;               // keys
+	if (int rc = grow_scratch(s, 5, n * sizeof(uint32_t))) return rc;               // order
+	if (int rc = grow_scratch(s, 6, SORT_BUCKETS * sizeof(uint32_t))) return rc;    // histogram / offsets
+	uint32_t* keys = static_cast<uint32_t*>(s->scratch[4]);
+	uint32_t* ord = static_cast<uint32_t*>(s->scratch[5]);
+	uint32_t* hist = static_cast<uint32_t*>(s->scratch[6]);
+	const PtxBvhNode& root = s->mesh_bvhs[0].nodes[0];
+	const float cells = float(1u << SORT_GRID_BITS);
+	float3 lo = make_float3(root.bmin[0], root.bmin[1], root.bmin[2]), scale;
+	const float ex = root.bmax[0] - root.bmin[0], ey = root.bmax[1] - root.bmin[1], ez = root.bmax[2] - root.bmin[2];
+	scale.x = ex > 0.0f ? cells / ex : 0.0f, scale.y = ey > 0.0f ? cells / ey : 0.0f, scale.z = ez > 0.0f ? cells / ez : 0.0f;
+	PTX_HIP(hipMemsetAsync(hist, 0, SORT_BUCKETS * sizeof(uint32_t), s->stream));
+	const dim3 block(256), grid(uint32_t((n + 255) / 256));
+	hipLaunchKernelGGL(k_sort_histogram, grid, block, 0, s->stream, d_rays, n, lo, scale, keys, hist);
+	hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SCAN_THREADS), 0, s->stream, hist);
+	hipLaunchKernelGGL(k_sort_scatter, grid, block, 0, s->stream, keys, n, hist, ord);
+	*order = ord;
+	return PTX_OK;
+}
+
 template<bool ANY>
-static int launch_persistent(PtxScene* s, bool culled, const PtxRay* d_rays, uint64_t n, PtxHit* d_hits, float* d_bary, uint32_t* d_inst, uint8_t* d_occ) {
+static int launch_persistent(PtxScene* s, bool culled, bool sort, const PtxRay* d_rays, uint64_t n, PtxHit* d_hits, float* d_bary, uint32_t* d_inst,
+                             uint8_t* d_occ) {
+	const uint32_t* order = nullptr;
+	if (sort && n >= (1u << 16) && n < (uint64_t(1) << 32))
+		if (int rc = sort_rays(s, d_rays, n, &order)) return rc;
 	if (!s->next_ray) {
 		void* p = nullptr;
 		PTX_HIP(hipMalloc(&p, 256));
@@ -363,11 +401,21 @@ static int launch_persistent(PtxScene* s, bool culled, const PtxRay* d_rays, uin
 		s->next_ray = static_cast<unsigned long long*>(p);
 	}
 	PTX_HIP(hipMemsetAsync(s->next_ray, 0, 256, s->stream));
+	if (n >= (uint64_t(1) << 32)) return fail(PTX_ERR_INVALID, "ray count too large for one launch");
+	if (int rc = grow_scratch(s, 7, n * sizeof(uint32_t))) return rc;   // rays deferred to the plain-division kernel
+	uint32_t* slow_list = static_cast<uint32_t*>(s->scratch[7]);
+	uint32_t* slow_count = reinterpret_cast<uint32_t*>(s->next_ray) + 16;   // same zeroed 256-byte block, its own 64-byte line
 	// enough 256-thread blocks to fill every CU at 8 waves per SIMD; each wave pulls rays until the pool is dry
 	const uint64_t want = (n + 255) / 256;
-	const dim3 block(256), grid(uint32_t(std::min<uint64_t>(want, uint64_t(s->cu_count) * 8)));
-	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray);
-	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray);
+	// Tuning knobs for experiments (not part of the ABI): blocks per CU and the refill threshold.
+	static const int blocks_per_cu = getenv("PTX_BLOCKS_PER_CU") ? atoi(getenv("PTX_BLOCKS_PER_CU")) : 8;
+	static const int refill = getenv("PTX_REFILL_MIN_IDLE") ? atoi(getenv("PTX_REFILL_MIN_IDLE")) : REFILL_MIN_IDLE;
+	const dim3 block(256), grid(uint32_t(std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu)))));
+	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count);
+	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count);
+	const dim3 dgrid(uint32_t(std::min<uint64_t>(want, 1024)));
+	if (culled) hipLaunchKernelGGL((k_mesh_deferred<MODE_CULLED, ANY>), dgrid, block, 0, s->stream, s->rec, d_rays, slow_list, slow_count, d_hits, d_bary, d_inst, d_occ);
+	else hipLaunchKernelGGL((k_mesh_deferred<MODE_REFERENCE, ANY>), dgrid, block, 0, s->stream, s->rec, d_rays, slow_list, slow_count, d_hits, d_bary, d_inst, d_occ);
 	return PTX_OK;
 }
 
@@ -651,7 +699,7 @@ int ptx_trace_closest(ptx_scene_t s, const PtxRay* rays, uint64_t n, PtxHit* hit
 	const dim3 block(256), grid(uint32_t((n + 255) / 256));
 	const bool culled = (flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED;
 	if (use_persistent(s) && !(flags & PTX_NO_PERSISTENT)) {
-		if (int rc = launch_persistent<false>(s, culled, d_rays, n, d_hits, d_bary, d_inst, nullptr)) return rc;
+		if (int rc = launch_persistent<false>(s, culled, !(flags & PTX_RAYS_COHERENT), d_rays, n, d_hits, d_bary, d_inst, nullptr)) return rc;
 	} else if (s->rec.mesh_only) {
 		if (culled) hipLaunchKernelGGL((k_trace_closest<MODE_CULLED, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
 		else hipLaunchKernelGGL((k_trace_closest<MODE_REFERENCE, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
@@ -689,7 +737,7 @@ int ptx_trace_any(ptx_scene_t s, const PtxRay* rays, uint64_t n, uint8_t* occlud
 	const dim3 block(256), grid(uint32_t((n + 255) / 256));
 	const bool culled = (flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED;
 	if (use_persistent(s) && !(flags & PTX_NO_PERSISTENT)) {
-		if (int rc = launch_persistent<true>(s, culled, d_rays, n, nullptr, nullptr, nullptr, d_occ)) return rc;
+		if (int rc = launch_persistent<true>(s, culled, !(flags & PTX_RAYS_COHERENT), d_rays, n, nullptr, nullptr, nullptr, d_occ)) return rc;
 	} else if (s->rec.mesh_only) {
 		if (culled) hipLaunchKernelGGL((k_trace_any<MODE_CULLED, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
 		else hipLaunchKernelGGL((k_trace_any<MODE_REFERENCE, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);

@@ -47,6 +47,7 @@ struct TraverseStats {
 	uint32_t nodes;   // interior nodes fetched (two box tests each)
 	uint32_t leaves;  // leaves entered
 	uint32_t tris;    // triangle tests
+	uint32_t max_sp;  // deepest stack seen
 };
 
 __device__ __forceinline__ float norm3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }  // vec3.h:155-160
@@ -122,11 +123,10 @@ __device__ __forceinline__ bool slab_test(float minx, float miny, float minz, fl
 	return true;
 }
 
-// Triangle::hit -- pathtracer/tri_mesh.cpp:46-111.
-__device__ __forceinline__ bool triangle_test(const TriGeom* __restrict__ tris, uint32_t index, const Ray3& r, float& distance,
-                                              float& t_out, float& u_out, float& v_out) {
-	const float4* p = reinterpret_cast<const float4*>(tris + index);
-	const float4 a = p[0], b = p[1], c = p[2];   // v0, e1, e2
+// Triangle::hit -- pathtracer/tri_mesh.cpp:46-111, on triangle data already in registers
+// (a = v0, b = e1, c = e2).
+__device__ __forceinline__ bool triangle_test(const float4 a, const float4 b, const float4 c, const Ray3& r, float& distance, float& t_out,
+                                              float& u_out, float& v_out) {
 	const float sx = r.ox - a.x, sy = r.oy - a.y, sz = r.oz - a.z;             // s = ray.point - v0
 	// cross(e1, dir)
 	const float c1x = b.y * r.dz - b.z * r.dy, c1y = b.z * r.dx - b.x * r.dz, c1z = b.x * r.dy - b.y * r.dx;
@@ -145,10 +145,31 @@ __device__ __forceinline__ bool triangle_test(const TriGeom* __restrict__ tris, 
 	return true;
 }
 
-struct Stack {
-	uint32_t ref[STACK_CAP];
-	float tnear[STACK_CAP];
+// Per-lane traversal stack.  The first LDS_SLOTS entries of a lane's stack live in LDS
+// (laid out [entry][thread], so the 64 lanes of a wave always touch 64 different banks
+// whatever their stack depths are), deeper entries in the lane's scratch memory.  A
+// near-first traversal rarely holds more than a dozen pending subtrees, so scratch traffic
+// (which costs HBM write bandwidth on every push) all but disappears.  LDS_SLOTS = 0 keeps
+// everything in scratch (kernels that do not reserve LDS).
+template<int LDS_SLOTS>
+struct StackT {
+	uint32_t ref[STACK_CAP - LDS_SLOTS];
+	float tnear[STACK_CAP - LDS_SLOTS];
+	uint32_t* lds_ref;    // &lds[threadIdx.x], stride blockDim.x
+	float* lds_tnear;
+	uint32_t stride;
+	__device__ __forceinline__ void push(int sp, uint32_t r, float t) {
+		if (LDS_SLOTS > 0 && sp < LDS_SLOTS) lds_ref[sp * stride] = r, lds_tnear[sp * stride] = t;
+		else ref[sp - LDS_SLOTS] = r, tnear[sp - LDS_SLOTS] = t;
+	}
+	__device__ __forceinline__ void push(int sp, uint32_t r) {
+		if (LDS_SLOTS > 0 && sp < LDS_SLOTS) lds_ref[sp * stride] = r;
+		else ref[sp - LDS_SLOTS] = r;
+	}
+	__device__ __forceinline__ uint32_t get_ref(int sp) const { return (LDS_SLOTS > 0 && sp < LDS_SLOTS) ? lds_ref[sp * stride] : ref[sp - LDS_SLOTS]; }
+	__device__ __forceinline__ float get_tnear(int sp) const { return (LDS_SLOTS > 0 && sp < LDS_SLOTS) ? lds_tnear[sp * stride] : tnear[sp - LDS_SLOTS]; }
 };
+using Stack = StackT<0>;
 
 // ---- traversal steps ------------------------------------------------------------------------
 // One traversal of PT::BVH<P>::hit / hitRecursive (bvh.cpp:246-375) over a flattened tree is a
@@ -169,38 +190,39 @@ __device__ __forceinline__ float cull_limit(const Ray3& r, bool run_hit, float r
 	return run_hit ? run_dist * CULL_SCALE + CULL_BIAS : INFINITY;
 }
 
-template<int MODE, bool ANY>
-__device__ __forceinline__ void pop_ref(const Ray3& r, Stack& st, const int base, int& sp, uint32_t& ref, bool run_hit, float run_dist) {
+template<int MODE, bool ANY, typename StackType>
+__device__ __forceinline__ void pop_ref(const Ray3& r, StackType& st, const int base, int& sp, uint32_t& ref, bool run_hit, float run_dist) {
 	for (;;) {
 		if (sp == base) {
 			ref = REF_DONE;
 			return;
 		}
 		--sp;
-		ref = st.ref[sp];
+		ref = st.get_ref(sp);
 		if (MODE == MODE_REFERENCE) {
 			if (run_hit && !(run_dist >= 0.0f)) continue;   // bvh.cpp:337-339
 			return;
 		} else {
-			if (!ANY && !(ref & REF_NOCULL) && st.tnear[sp] > cull_limit<ANY>(r, run_hit, run_dist)) continue;
+			if (!ANY && !(ref & REF_NOCULL) && st.get_tnear(sp) > cull_limit<ANY>(r, run_hit, run_dist)) continue;
 			return;
 		}
 	}
 }
 
-template<int MODE, bool ANY, bool FAST, bool STATS>
-__device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const Ray3& r, const RayInv& inv, Stack& st, const int base, int& sp,
+template<int MODE, bool ANY, bool FAST, bool STATS, typename StackType>
+__device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const Ray3& r, const RayInv& inv, StackType& st, const int base, int& sp,
                                           uint32_t& ref, bool run_hit, float run_dist, TraverseStats* stats) {
 	const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
 	const float4 n0 = p[0], n1 = p[1], n2 = p[2];
 	const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
 	if (STATS) stats->nodes++;
+	if (STATS) stats->max_sp = max(stats->max_sp, uint32_t(sp - base));
 	float tl, tr;
 	const bool hl = slab_test<FAST>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl);
 	const bool hr = slab_test<FAST>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr);
 	if (MODE == MODE_REFERENCE) {
 		if (hl) {
-			if (hr) st.ref[sp++] = kids.y;
+			if (hr) st.push(sp++, kids.y);
 			ref = kids.x;
 		} else if (hr && !(run_hit && !(run_dist >= 0.0f))) {
 			ref = kids.y;
@@ -212,8 +234,7 @@ __device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const
 		const bool gl = hl && ((kids.x & REF_NOCULL) || !(tl > limit)), gr = hr && ((kids.y & REF_NOCULL) || !(tr > limit));
 		if (gl && gr) {
 			const bool left_first = !(tr < tl);
-			st.ref[sp] = left_first ? kids.y : kids.x;
-			st.tnear[sp] = left_first ? tr : tl;
+			st.push(sp, left_first ? kids.y : kids.x, left_first ? tr : tl);
 			sp++;
 			ref = left_first ? kids.x : kids.y;
 		} else if (gl) {
@@ -231,8 +252,8 @@ __device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const
 // primitive-test code each run with as many lanes active as possible.
 //   leaf(first, count) -> bool   tests primitives [first, first+count) in array order, folds them
 //                                into the caller's running hit, returns true to stop (ANY mode)
-template<int MODE, bool ANY, bool FAST, bool STATS, typename Leaf>
-__device__ __forceinline__ void traverse_tree(const Node2* __restrict__ nodes, uint32_t root_ref, const Ray3& r, const RayInv& inv, Stack& st,
+template<int MODE, bool ANY, bool FAST, bool STATS, typename Leaf, typename StackType>
+__device__ __forceinline__ void traverse_tree(const Node2* __restrict__ nodes, uint32_t root_ref, const Ray3& r, const RayInv& inv, StackType& st,
                                               const int base, Leaf&& leaf, const bool& run_hit, const float& run_dist, TraverseStats* stats) {
 	int sp = base;
 	uint32_t ref = root_ref;
@@ -246,13 +267,22 @@ __device__ __forceinline__ void traverse_tree(const Node2* __restrict__ nodes, u
 }
 
 // Triangles [first, first+count) of a mesh folded into the running hit, in array order.
+// The next triangle's three 16-byte loads are in flight while the current one is tested, so a
+// leaf costs about one memory round trip, not one per triangle, at the price of one extra
+// triangle's worth of registers.
 template<int MODE, bool ANY, bool STATS>
 __device__ __forceinline__ bool mesh_leaf(const TriGeom* __restrict__ tris, uint32_t first, uint32_t count, const Ray3& r, MeshHit& cur,
                                           TraverseStats* stats) {
-	for (uint32_t i = first; i < first + count; i++) {
+	if (count == 0) return false;
+	const float4* p = reinterpret_cast<const float4*>(tris + first);
+	float4 a = p[0], b = p[1], c = p[2];
+	for (uint32_t k = 0; k < count; k++) {
+		float4 na = a, nb = b, nc = c;
+		if (k + 1 < count) na = p[3 * (k + 1)], nb = p[3 * (k + 1) + 1], nc = p[3 * (k + 1) + 2];
+		const uint32_t i = first + k;
 		float d, t, u, v;
 		if (STATS) stats->tris++;
-		if (triangle_test(tris, i, r, d, t, u, v)) {
+		if (triangle_test(a, b, c, r, d, t, u, v)) {
 			// Trace::min(cur, candidate), trace.h:28-36: the candidate replaces the running hit unless
 			// the running hit is strictly closer.  In array order that leaves, among equal distances,
 			// the largest array position; the culled mode visits in another order and asks for that
@@ -264,13 +294,14 @@ __device__ __forceinline__ bool mesh_leaf(const TriGeom* __restrict__ tris, uint
 		} else if (!cur.hit) {
 			cur.distance = 0.0f;   // Trace::min of two misses is a default Trace (trace.h:35)
 		}
+		a = na, b = nb, c = nc;
 	}
 	return false;
 }
 
 // PT::BVH<Triangle>::hit (bvh.cpp:246-270) or List<Triangle>::hit (list.h:25-32) for one mesh.
-template<int MODE, bool ANY, bool STATS>
-__device__ __forceinline__ void traverse_mesh(const SceneRec& sc, const MeshRec& mesh, const Ray3& r, Stack& st, int base, MeshHit& cur,
+template<int MODE, bool ANY, bool STATS, typename StackType>
+__device__ __forceinline__ void traverse_mesh(const SceneRec& sc, const MeshRec& mesh, const Ray3& r, StackType& st, int base, MeshHit& cur,
                                               TraverseStats* stats) {
 	const TriGeom* __restrict__ tris = sc.tris + mesh.tri_base;
 	auto leaf = [&](uint32_t first, uint32_t count) -> bool { return mesh_leaf<MODE, ANY, STATS>(tris, first, count, r, cur, stats); };

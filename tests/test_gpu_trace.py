@@ -13,7 +13,8 @@ from pathtracer_amd import abi, capi, synth
 pytestmark = pytest.mark.gpu
 
 MODES = [abi.PTX_TRAVERSE_REFERENCE, abi.PTX_TRAVERSE_CULLED,
-         abi.PTX_TRAVERSE_REFERENCE | abi.PTX_NO_PERSISTENT, abi.PTX_TRAVERSE_CULLED | abi.PTX_NO_PERSISTENT]
+         abi.PTX_TRAVERSE_REFERENCE | abi.PTX_NO_PERSISTENT, abi.PTX_TRAVERSE_CULLED | abi.PTX_NO_PERSISTENT,
+         abi.PTX_TRAVERSE_CULLED | abi.PTX_RAYS_COHERENT]
 
 
 def assert_same_hits(got, want, what):
@@ -50,7 +51,7 @@ def test_mesh_closest_hit_matches_checker(oracle, name, use_bvh):
     assert np.array_equal(scene.mesh_order(len(idx)), want_scene.mesh_order(len(idx)))
     lo = verts[:, :3].min(0) if len(verts) else np.zeros(3)
     hi = verts[:, :3].max(0) if len(verts) else np.ones(3)
-    rays = synth.rays(1 << 14, key=31)
+    rays = synth.rays(1 << 17, key=31)   # large enough for the library's ray-grouping pass to run
     rays["o"] = lo + (rays["o"] / 10.0) * (hi - lo) * 1.2 - 0.1 * (hi - lo)
     # axis-aligned directions and origins on box planes: the 0/0 and x/0 paths of the slab test
     rays["d"][:64] = np.eye(3, dtype=np.float32)[np.arange(64) % 3]

@@ -16,7 +16,8 @@
 
 namespace ptx {
 
-constexpr int REFILL_MIN_IDLE = 20;   // refill when at least this many of the 64 slots are dry
+constexpr int REFILL_MIN_IDLE = 8;    // refill when at least this many of the 64 slots are dry
+constexpr int TRI_MIN_LANES = 1;      // run the triangle step when at least this many lanes stand in a leaf
 constexpr int PERSISTENT_LDS_SLOTS = 12;   // stack entries per lane kept in LDS (8 B each)
 constexpr unsigned long long WAVE_CHUNK = 256;    // consecutive ray slots a wave claims at a time
 
@@ -24,7 +25,8 @@ template<int MODE, bool ANY>
 __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, PtxHit* __restrict__ hits,
                                                          float* __restrict__ bary, uint32_t* __restrict__ inst, uint8_t* __restrict__ occluded,
                                                          unsigned long long* __restrict__ next_ray, const int refill_min_idle,
-                                                         const uint32_t* __restrict__ order, uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count) {
+                                                         const uint32_t* __restrict__ order, uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count,
+                                                         const int tri_min_lanes) {
 	const MeshRec mesh = sc.meshes[0];
 	const TriGeom* __restrict__ tris = sc.tris + mesh.tri_base;
 	const Node2* __restrict__ nodes = sc.nodes + mesh.node_base;
@@ -33,8 +35,8 @@ __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxR
 
 	__shared__ uint32_t lds_ref[PERSISTENT_LDS_SLOTS * 256];
 	__shared__ float lds_tnear[PERSISTENT_LDS_SLOTS * 256];
-	StackT<PERSISTENT_LDS_SLOTS> st;
-	st.lds_ref = lds_ref + threadIdx.x, st.lds_tnear = lds_tnear + threadIdx.x, st.stride = 256;
+	Stack spill;
+	LdsStack<PERSISTENT_LDS_SLOTS, 256> st{lds_ref + threadIdx.x, lds_tnear + threadIdx.x, &spill};
 	int sp = 0;
 	uint32_t ref = REF_DONE;          // REF_DONE + have_ray == false: the slot is dry
 	uint32_t tri_k = 0;               // next triangle of the leaf `ref` stands in
@@ -112,13 +114,17 @@ __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxR
 		// node, then one triangle for the lanes standing in a leaf.  The load/return path of the
 		// CU's vector memory pipeline is paid per wave instruction, however few lanes are active,
 		// so the step is shaped to advance as many lanes as possible per memory instruction.
-		if (__ballot(!(ref & REF_LEAF)) != 0ull) {
+		const unsigned long long on_node = __ballot(!(ref & REF_LEAF));
+		if (on_node != 0ull) {
 			if (!(ref & REF_LEAF)) {
 				node_step<MODE, ANY, true, false>(nodes, r, inv, st, 0, sp, ref, cur.hit, cur.distance, nullptr);
 				tri_k = 0;
 			}
 		}
-		if (__ballot(ref != REF_DONE && (ref & REF_LEAF)) != 0ull) {
+		// The triangle step waits until enough lanes want it (or nobody has box work left): it then
+		// runs less often and fuller.
+		const int in_leaf = __popcll(__ballot(ref != REF_DONE && (ref & REF_LEAF)));
+		if (in_leaf >= tri_min_lanes || (in_leaf > 0 && on_node == 0ull)) {
 			if (ref != REF_DONE && (ref & REF_LEAF)) {
 				const uint32_t first = (ref & REF_INDEX_MASK) >> 4, count = ref & 15u;
 				bool stop = false;

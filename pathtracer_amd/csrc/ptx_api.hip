@@ -410,9 +410,10 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const PtxRay* 
 	// Tuning knobs for experiments (not part of the ABI): blocks per CU and the refill threshold.
 	static const int blocks_per_cu = getenv("PTX_BLOCKS_PER_CU") ? atoi(getenv("PTX_BLOCKS_PER_CU")) : 8;
 	static const int refill = getenv("PTX_REFILL_MIN_IDLE") ? atoi(getenv("PTX_REFILL_MIN_IDLE")) : REFILL_MIN_IDLE;
+	static const int tri_min = getenv("PTX_TRI_MIN_LANES") ? atoi(getenv("PTX_TRI_MIN_LANES")) : TRI_MIN_LANES;
 	const dim3 block(256), grid(uint32_t(std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu)))));
-	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count);
-	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count);
+	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min);
+	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min);
 	const dim3 dgrid(uint32_t(std::min<uint64_t>(want, 1024)));
 	if (culled) hipLaunchKernelGGL((k_mesh_deferred<MODE_CULLED, ANY>), dgrid, block, 0, s->stream, s->rec, d_rays, slow_list, slow_count, d_hits, d_bary, d_inst, d_occ);
 	else hipLaunchKernelGGL((k_mesh_deferred<MODE_REFERENCE, ANY>), dgrid, block, 0, s->stream, s->rec, d_rays, slow_list, slow_count, d_hits, d_bary, d_inst, d_occ);

@@ -145,31 +145,42 @@ __device__ __forceinline__ bool triangle_test(const float4 a, const float4 b, co
 	return true;
 }
 
-// Per-lane traversal stack.  The first LDS_SLOTS entries of a lane's stack live in LDS
-// (laid out [entry][thread], so the 64 lanes of a wave always touch 64 different banks
-// whatever their stack depths are), deeper entries in the lane's scratch memory.  A
-// near-first traversal rarely holds more than a dozen pending subtrees, so scratch traffic
-// (which costs HBM write bandwidth on every push) all but disappears.  LDS_SLOTS = 0 keeps
-// everything in scratch (kernels that do not reserve LDS).
-template<int LDS_SLOTS>
-struct StackT {
-	uint32_t ref[STACK_CAP - LDS_SLOTS];
-	float tnear[STACK_CAP - LDS_SLOTS];
-	uint32_t* lds_ref;    // &lds[threadIdx.x], stride blockDim.x
+// Per-lane traversal stacks.
+//
+// Stack: everything in the lane's scratch memory.
+//
+// LdsStack: the first LDS_SLOTS entries of a lane's stack live in LDS (laid out
+// [entry][thread], so the 64 lanes of a wave always touch 64 different banks whatever their
+// stack depths are), deeper entries in a scratch Stack it points to.  A near-first traversal
+// rarely holds more than a dozen pending subtrees, so scratch traffic (HBM write bandwidth on
+// every push, and a vector-memory instruction each way) all but disappears.  The LDS pointers
+// sit in their own small object, apart from the dynamically indexed arrays, so the compiler
+// keeps them in registers.
+struct Stack {
+	uint32_t ref[STACK_CAP];
+	float tnear[STACK_CAP];
+	__device__ __forceinline__ void push(int sp, uint32_t r, float t) { ref[sp] = r, tnear[sp] = t; }
+	__device__ __forceinline__ void push(int sp, uint32_t r) { ref[sp] = r; }
+	__device__ __forceinline__ uint32_t get_ref(int sp) const { return ref[sp]; }
+	__device__ __forceinline__ float get_tnear(int sp) const { return tnear[sp]; }
+};
+
+template<int LDS_SLOTS, int STRIDE>
+struct LdsStack {
+	uint32_t* lds_ref;    // &lds_ref_array[threadIdx.x]
 	float* lds_tnear;
-	uint32_t stride;
+	Stack* spill;
 	__device__ __forceinline__ void push(int sp, uint32_t r, float t) {
-		if (LDS_SLOTS > 0 && sp < LDS_SLOTS) lds_ref[sp * stride] = r, lds_tnear[sp * stride] = t;
-		else ref[sp - LDS_SLOTS] = r, tnear[sp - LDS_SLOTS] = t;
+		if (sp < LDS_SLOTS) lds_ref[sp * STRIDE] = r, lds_tnear[sp * STRIDE] = t;
+		else spill->push(sp - LDS_SLOTS, r, t);
 	}
 	__device__ __forceinline__ void push(int sp, uint32_t r) {
-		if (LDS_SLOTS > 0 && sp < LDS_SLOTS) lds_ref[sp * stride] = r;
-		else ref[sp - LDS_SLOTS] = r;
+		if (sp < LDS_SLOTS) lds_ref[sp * STRIDE] = r;
+		else spill->push(sp - LDS_SLOTS, r);
 	}
-	__device__ __forceinline__ uint32_t get_ref(int sp) const { return (LDS_SLOTS > 0 && sp < LDS_SLOTS) ? lds_ref[sp * stride] : ref[sp - LDS_SLOTS]; }
-	__device__ __forceinline__ float get_tnear(int sp) const { return (LDS_SLOTS > 0 && sp < LDS_SLOTS) ? lds_tnear[sp * stride] : tnear[sp - LDS_SLOTS]; }
+	__device__ __forceinline__ uint32_t get_ref(int sp) const { return sp < LDS_SLOTS ? lds_ref[sp * STRIDE] : spill->get_ref(sp - LDS_SLOTS); }
+	__device__ __forceinline__ float get_tnear(int sp) const { return sp < LDS_SLOTS ? lds_tnear[sp * STRIDE] : spill->get_tnear(sp - LDS_SLOTS); }
 };
-using Stack = StackT<0>;
 
 // ---- traversal steps ------------------------------------------------------------------------
 // One traversal of PT::BVH<P>::hit / hitRecursive (bvh.cpp:246-375) over a flattened tree is a

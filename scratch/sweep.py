@@ -18,7 +18,7 @@ e0.record()
 for _ in range(5): scene.trace_closest_device(rays, hits, flags=flags, n=n)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
-print(f"blocks/CU={os.environ.get('PTX_BLOCKS_PER_CU','8')} refill={os.environ.get('PTX_REFILL_MIN_IDLE','20')}: {ms:.2f} ms  {n/ms/1e3:.1f} Mrays/s", flush=True)
+print(f"tri_min={os.environ.get('PTX_TRI_MIN_LANES','1')} blocks/CU={os.environ.get('PTX_BLOCKS_PER_CU','8')} refill={os.environ.get('PTX_REFILL_MIN_IDLE','20')}: {ms:.2f} ms  {n/ms/1e3:.1f} Mrays/s", flush=True)
 flags |= abi.PTX_RAYS_COHERENT
 for _ in range(2): scene.trace_closest_device(rays, hits, flags=flags, n=n)
 torch.cuda.synchronize()

@@ -88,12 +88,18 @@ struct SceneRec {
 	uint32_t pad;
 };
 
-// Hit record passed from the extend stage to the shade stage.
-struct HitRec {
-	float distance;
+// Hit record passed from the extend stage to the shade stage (two 16-byte stores).
+// `t` is the ray parameter in the space the primitive was intersected in: the shade stage
+// rebuilds Trace::position as point + dir * t there (tri_mesh.cpp:91-99) and carries it to
+// world space (trace.h:38-43).
+struct alignas(16) HitRec {
+	float distance;   // world-space Trace::distance
+	float t;
+	float u, v;
 	uint32_t prim;    // BVH-order index within the mesh, or 0xFFFFFFFF
 	uint32_t inst;    // BVH-order instance index
-	float u, v;
+	uint32_t pad[2];
 };
+static_assert(sizeof(HitRec) == 32, "");
 
 }  // namespace ptx

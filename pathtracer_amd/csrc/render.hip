@@ -1,6 +1,404 @@
-// render.hip -- wavefront path tracing pipeline (placeholder until the pipeline lands).
-#include "scene.h"
+// render.hip -- Pathtracer::do_trace / trace / accumulate as a wavefront pipeline.
+//
+// The reference traces one camera sample at a time, recursively (pathtracer.cpp:126-173,
+// 444-477).  Its recursion is linear: at every vertex one "direct" ray of depth 0, whose
+// `.first` (the emission it meets) is used, and one "indirect" ray that continues the path.
+// Here every pixel of every tile in the batch is a SLOT.  For sample k of the tiles, all
+// slots run in lock step through
+//
+//   raygen  -> [ extend -> shade/scatter -> compact ] x (max_ray_depth + 1) -> add to slot sum
+//
+//   raygen   camera ray per slot (Camera::sample_ray, 2 draws), every slot into the active list
+//   extend   closest hit of each active path's main ray and, when it has one, its direct ray
+//   shade    uses the two hits: adds the direct ray's emission, shades the main ray's vertex
+//            (emission, delta lights with inline occlusion queries, BSDF scatter twice), writes
+//            the next main + direct rays; finished paths add their sample to the slot's float
+//            sum; surviving paths are appended to the next active list with one atomic per wave
+//            (ballot + prefix popcount)
+//
+// Samples of a slot are added in sample order (sample k is complete before k+1 starts), so a
+// slot's float sum is the same sequence of additions as the reference's tile-private
+// HDR_Image pixel (pathtracer.cpp:447-470).  When the tile's samples are done the sum goes to
+// the 40.24 fixed-point accumulator exactly as Pathtracer::accumulate does
+// (pathtracer.cpp:407-427); integer atomics make tiles that share pixels commute.
+//
+// Randomness: one Philox-4x32-10 stream per (pixel, sample); the draws are consumed in the
+// order the reference's recursion consumes RNG::unit().
+#include <hip/hip_runtime.h>
 
-extern "C" int ptx_render_tiles(ptx_scene_t, const PtxCamera*, const PtxTile*, uint32_t, uint64_t, int64_t*, uint32_t*, uint32_t) {
-	return ptx::fail(PTX_ERR_UNSUPPORTED, "ptx_render_tiles: not built yet");
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "scene.h"
+#include "shade.hip.h"
+#include "traverse.hip.h"
+
+namespace ptx {
+
+constexpr float RAY_MINIMUM_BOUND = 0.001f;   // pathtracer.cpp:17
+constexpr uint32_t FLAG_CAMERA = 1u, FLAG_HAS_DIRECT = 2u;
+constexpr uint64_t MAX_SLOTS_PER_CHUNK = 8u << 20;
+
+struct SlotInfo {
+	uint32_t pixel, s_begin, s_count, pad;
+};
+
+struct PathState {            // 64 bytes per slot
+	float T[3];               // throughput of the main ray's path so far
+	uint32_t depth;           // Ray::depth of the main ray
+	float L[3];               // radiance gathered so far
+	uint32_t draws;           // random numbers consumed so far
+	float Wd[3];              // weight of the pending direct ray's emission (T * attenuation [/ pdf])
+	uint32_t flags;
+	uint32_t sample, pad[3];
+};
+
+struct TileRec {
+	uint32_t x_begin, y_begin, w, h, s_begin, s_count, slot_base, pad;
+};
+
+struct RenderBuffers {
+	SlotInfo* slots;
+	float4* sums;         // per slot: float sum of its samples so far (rgb)
+	PathState* paths;
+	PtxRay* rays;         // 2 per slot: main, direct
+	HitRec* hits;         // 2 per slot
+	uint32_t* active[2];
+	uint32_t* counts;     // [0], [1]: sizes of active[0], active[1]
+};
+
+__global__ void __launch_bounds__(256) k_init_slots(const TileRec* __restrict__ tiles, uint32_t film_w, RenderBuffers rb) {
+	const TileRec t = tiles[blockIdx.x];
+	for (uint32_t p = threadIdx.x; p < t.w * t.h; p += blockDim.x) {
+		const uint32_t x = t.x_begin + p % t.w, y = t.y_begin + p / t.w;
+		rb.slots[t.slot_base + p] = SlotInfo{y * film_w + x, t.s_begin, t.s_count, 0};
+		rb.sums[t.slot_base + p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	}
+}
+
+// Appends `value` for every lane with `keep` set: one atomic per wave.
+__device__ __forceinline__ void wave_append(bool keep, uint32_t value, uint32_t* list, uint32_t* count) {
+	const unsigned long long mask = __ballot(keep);
+	if (mask == 0ull) return;
+	const unsigned lane = threadIdx.x & 63u;
+	const unsigned leader = __ffsll((long long)mask) - 1;
+	uint32_t base = 0;
+	if (lane == leader) base = atomicAdd(count, uint32_t(__popcll(mask)));
+	base = __shfl(base, leader);
+	if (keep) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+// Camera::sample_ray for sample `k` of every slot that has one (pathtracer.cpp:448-454).
+__global__ void __launch_bounds__(256) k_raygen(RenderBuffers rb, uint32_t n_slots, uint32_t k, CameraRec cam, uint32_t key0, uint32_t key1,
+                                                uint32_t* __restrict__ out_list, uint32_t* __restrict__ out_count) {
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	bool live = false;
+	if (slot < n_slots) {
+		const SlotInfo si = rb.slots[slot];
+		if (k < si.s_count) {
+			live = true;
+			PathRng rng;
+			rng.start(key0, key1, si.pixel, si.s_begin + k, 0);
+			const float ox = rng.next_unit(), oy = rng.next_unit();   // Samplers::Rect::sample, samplers.cpp:13 (x first)
+			const Ray3 r = camera_ray(cam, si.pixel % cam.film_w, si.pixel / cam.film_w, ox, oy);
+			PathState ps{};
+			ps.T[0] = ps.T[1] = ps.T[2] = 1.0f;
+			ps.depth = cam.max_depth;
+			ps.draws = rng.draws;
+			ps.flags = FLAG_CAMERA;
+			ps.sample = si.s_begin + k;
+			rb.paths[slot] = ps;
+			rb.rays[2 * slot] = PtxRay{{r.ox, r.oy, r.oz}, {r.dx, r.dy, r.dz}, r.tmin, r.tmax};
+		}
+	}
+	wave_append(live, slot, out_list, out_count);
+}
+
+// Closest hit for the main ray of every active path and for its direct ray when it has one.
+template<int MODE>
+__global__ void __launch_bounds__(256) k_extend(SceneRec sc, RenderBuffers rb, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count) {
+	const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+	if ((item >> 1) >= *count) return;
+	const uint32_t slot = list[item >> 1], which = item & 1u;
+	if (which == 1u && !(rb.paths[slot].flags & FLAG_HAS_DIRECT)) return;
+	const float4* rp = reinterpret_cast<const float4*>(rb.rays + 2 * slot + which);
+	const float4 a = rp[0], b = rp[1];
+	Ray3 r{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	Stack st;
+	SceneHit h;
+	traverse_scene<MODE, false>(sc, r, st, h);
+	HitRec out{};
+	out.distance = h.distance, out.t = h.t, out.u = h.u, out.v = h.v;
+	out.prim = h.hit ? h.prim : 0xFFFFFFFFu, out.inst = h.inst;
+	rb.hits[2 * slot + which] = out;
+}
+
+// What Pathtracer::trace needs of a Trace (trace.h:20-26) rebuilt from a HitRec.
+struct Surface {
+	V3f position, normal;
+	float u, v;
+	int32_t material;
+};
+
+__device__ __forceinline__ Surface rebuild_surface(const SceneRec& sc, const ShadeTables& sh, const Ray3& world, const HitRec& h) {
+	Surface s;
+	const InstRec& in = sc.insts[h.inst];
+	Ray3 r = world;
+	if (in.has_transform) r = ray_transform(in.iT, world);   // Instance::hit, instance.h:33
+	V3f pos = v3(r.ox, r.oy, r.oz) + v3(r.dx, r.dy, r.dz) * h.t;   // ray.point + dir * t
+	V3f nrm;
+	if (in.mesh >= 0) {
+		const TriAttr& at = sh.attrs[sc.meshes[in.mesh].tri_base + h.prim];
+		const float w = 1 - h.u - h.v;   // tri_mesh.cpp:100-101
+		nrm = w * v3(at.n0[0], at.n0[1], at.n0[2]) + h.u * v3(at.n1[0], at.n1[1], at.n1[2]) + h.v * v3(at.n2[0], at.n2[1], at.n2[2]);
+		s.u = (w * at.uv0[0] + h.u * at.uv1[0]) + h.v * at.uv2[0];
+		s.v = (w * at.uv0[1] + h.u * at.uv1[1]) + h.v * at.uv2[1];
+	} else {
+		nrm = unit(pos);   // shape.cpp:80-81
+		sphere_uv(nrm, s.u, s.v);
+	}
+	if (in.has_transform) {   // Trace::transform(T, iT.T()), trace.h:38-43
+		mat_point(in.T, pos.x, pos.y, pos.z, pos.x, pos.y, pos.z);
+		// N = iT.T(): its columns are the rows of iT
+		const float* m = in.iT;
+		const V3f n = nrm;
+		nrm.x = ((n.x * m[0] + n.y * m[1]) + n.z * m[2]) + 0.0f * m[3];
+		nrm.y = ((n.x * m[4] + n.y * m[5]) + n.z * m[6]) + 0.0f * m[7];
+		nrm.z = ((n.x * m[8] + n.y * m[9]) + n.z * m[10]) + 0.0f * m[11];
+		nrm = unit(nrm);
+	}
+	s.position = pos, s.normal = nrm, s.material = in.material;
+	return s;
+}
+
+// The body of Pathtracer::trace for one active path, one recursion level per launch.
+template<int MODE>
+__global__ void __launch_bounds__(256) k_shade(SceneRec sc, ShadeTables sh, RenderBuffers rb, const uint32_t* __restrict__ list,
+                                               const uint32_t* __restrict__ count, uint32_t key0, uint32_t key1,
+                                               uint32_t* __restrict__ next_list, uint32_t* __restrict__ next_count) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	bool alive = false;
+	uint32_t slot = 0;
+	if (i < *count) {
+		slot = list[i];
+		PathState ps = rb.paths[slot];
+		V3f T = v3(ps.T[0], ps.T[1], ps.T[2]), L = v3(ps.L[0], ps.L[1], ps.L[2]);
+
+		// ---- the direct ray traced last round: trace(rng, new_in_ray).first (pathtracer.cpp:71-76)
+		if (ps.flags & FLAG_HAS_DIRECT) {
+			const PtxRay dr = rb.rays[2 * slot + 1];
+			const HitRec dh = rb.hits[2 * slot + 1];
+			V3f first = v3(0, 0, 0);
+			if (dh.prim == 0xFFFFFFFFu) {
+				first = env_radiance(sh, v3(dr.d[0], dr.d[1], dr.d[2]));   // pathtracer.cpp:129-136
+			} else {
+				const Ray3 r{dr.o[0], dr.o[1], dr.o[2], dr.d[0], dr.d[1], dr.d[2], dr.tmin, dr.tmax};
+				const Surface s = rebuild_surface(sc, sh, r, dh);
+				if (s.material >= 0) first = bsdf_emission(sh, sh.materials[s.material], s.u, s.v);   // depth 0: {emissive, {}} (pathtracer.cpp:160-163)
+			}
+			L = L + first * v3(ps.Wd[0], ps.Wd[1], ps.Wd[2]);
+		}
+
+		// ---- the main ray
+		const PtxRay mr = rb.rays[2 * slot];
+		const HitRec mh = rb.hits[2 * slot];
+		const V3f ray_o = v3(mr.o[0], mr.o[1], mr.o[2]), ray_d = v3(mr.d[0], mr.d[1], mr.d[2]);
+		const bool camera = ps.flags & FLAG_CAMERA;
+		ps.flags = 0;
+		if (mh.prim == 0xFFFFFFFFu || sc.insts[mh.inst].material < 0) {
+			// miss: {env, {}} -- only a camera ray's (or a direct ray's) `.first` is ever used
+			if (camera && mh.prim == 0xFFFFFFFFu) L = L + env_radiance(sh, ray_d);
+		} else {
+			const Ray3 r{mr.o[0], mr.o[1], mr.o[2], mr.d[0], mr.d[1], mr.d[2], mr.tmin, mr.tmax};
+			Surface s = rebuild_surface(sc, sh, r, mh);
+			const MatRec m = sh.materials[s.material];
+			if (!mat_is_sided(m.type) && dot3(s.normal, ray_d) > 0.0f) s.normal = -s.normal;   // pathtracer.cpp:143-145
+			const Frame f = frame_from_normal(s.normal);
+			const V3f out_dir = unit(f.to_local(ray_o - s.position));   // pathtracer.cpp:153
+			const V3f emissive = bsdf_emission(sh, m, s.u, s.v);
+			if (camera) L = L + emissive;   // an indirect ray contributes `.second` only
+			if (ps.depth != 0 && m.type != PTX_MAT_EMISSIVE) {   // pathtracer.cpp:163
+				// sum_delta_lights (pathtracer.cpp:645-666)
+				if (!mat_is_specular(m.type)) {
+					for (uint32_t li = 0; li < sh.n_delta_lights; li++) {
+						const IncomingRec inc = light_incoming(sh.delta_lights[li], s.position);
+						const V3f in_dir = f.to_local(inc.direction);
+						const V3f att = bsdf_evaluate(sh, m, in_dir, s.u, s.v);   // evaluate(out_dir, in_dir): cosine of in_dir
+						if (0.2126f * att.x + 0.7152f * att.y + 0.0722f * att.z == 0.0f) continue;
+						const V3f sd = unit(inc.direction);   // Ray's constructor
+						const Ray3 shadow{s.position.x, s.position.y, s.position.z, sd.x, sd.y, sd.z, SH_EPS, inc.distance - SH_EPS};
+						Stack st;
+						SceneHit occ;
+						traverse_scene<MODE, true>(sc, shadow, st, occ);
+						if (!occ.hit) L = L + T * (att * inc.radiance);
+					}
+				}
+				PathRng rng;
+				rng.start(key0, key1, rb.slots[slot].pixel, ps.sample, ps.draws);
+				// sample_direct_lighting_task4 (pathtracer.cpp:34-78): weight = attenuation [/ pdf]
+				{
+					const ScatterRec sc1 = bsdf_scatter(sh, m, rng, out_dir, s.u, s.v);
+					const V3f in_world = unit(f.to_world(sc1.direction));   // Ray's constructor normalises
+					V3f w = sc1.specular ? sc1.attenuation : bsdf_evaluate(sh, m, out_dir, s.u, s.v);   // evaluate(in_dir, out_dir): `in` = out_dir
+					if (!sc1.specular) w = w / bsdf_pdf(m, out_dir);                                      // pdf(in_dir, out_dir): `in` = out_dir
+					const V3f Wd = T * w;
+					ps.Wd[0] = Wd.x, ps.Wd[1] = Wd.y, ps.Wd[2] = Wd.z;
+					rb.rays[2 * slot + 1] = PtxRay{{s.position.x, s.position.y, s.position.z}, {in_world.x, in_world.y, in_world.z}, RAY_MINIMUM_BOUND, INFINITY};
+					ps.flags |= FLAG_HAS_DIRECT;
+				}
+				// sample_indirect_lighting (pathtracer.cpp:81-124)
+				{
+					const ScatterRec sc2 = bsdf_scatter(sh, m, rng, out_dir, s.u, s.v);
+					const V3f in_world = unit(f.to_world(sc2.direction));
+					V3f w = sc2.specular ? sc2.attenuation : bsdf_evaluate(sh, m, out_dir, s.u, s.v);
+					if (!sc2.specular) w = w / bsdf_pdf(m, out_dir);
+					T = T * w;
+					rb.rays[2 * slot] = PtxRay{{s.position.x, s.position.y, s.position.z}, {in_world.x, in_world.y, in_world.z}, RAY_MINIMUM_BOUND, INFINITY};
+					ps.depth -= 1;
+				}
+				ps.draws = rng.draws;
+				alive = true;
+			}
+		}
+		if (alive) {
+			ps.T[0] = T.x, ps.T[1] = T.y, ps.T[2] = T.z, ps.L[0] = L.x, ps.L[1] = L.y, ps.L[2] = L.z;
+			rb.paths[slot] = ps;
+		} else {
+			// `if (p.valid()) sample.at(px, py) += p;` (pathtracer.cpp:466-470); pdf of the camera sample is 1
+			if (finite3(L)) {
+				float4 sum = rb.sums[slot];
+				sum.x += L.x, sum.y += L.y, sum.z += L.z;
+				rb.sums[slot] = sum;
+			}
+		}
+	}
+	wave_append(alive, slot, next_list, next_count);
+}
+
+// Pathtracer::accumulate (pathtracer.cpp:407-427)
+__global__ void __launch_bounds__(256) k_flush(RenderBuffers rb, uint32_t n_slots, unsigned long long* __restrict__ accum, uint32_t* __restrict__ samples) {
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= n_slots) return;
+	const SlotInfo si = rb.slots[slot];
+	const float4 sum = rb.sums[slot];
+	const float scale = float(1ll << 24);   // n.r * (1ll << 24ll): the integer converts to float
+	atomicAdd(&accum[size_t(si.pixel) * 3 + 0], (unsigned long long)(long long)(sum.x * scale));
+	atomicAdd(&accum[size_t(si.pixel) * 3 + 1], (unsigned long long)(long long)(sum.y * scale));
+	atomicAdd(&accum[size_t(si.pixel) * 3 + 2], (unsigned long long)(long long)(sum.z * scale));
+	atomicAdd(&samples[si.pixel], si.s_count);
+}
+
+static int device_alloc(PtxScene* s, int slot, size_t bytes, void** out) {
+	if (s->scratch_bytes[slot] < bytes) {
+		if (s->scratch[slot]) PTX_HIP(hipFree(s->scratch[slot]));
+		s->scratch[slot] = nullptr, s->scratch_bytes[slot] = 0;
+		PTX_HIP(hipMalloc(&s->scratch[slot], bytes));
+		s->scratch_bytes[slot] = bytes;
+	}
+	*out = s->scratch[slot];
+	return PTX_OK;
+}
+
+}  // namespace ptx
+
+using namespace ptx;
+
+extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTile* tiles, uint32_t n_tiles, uint64_t seed, int64_t* accum_rgb,
+                                uint32_t* samples, uint32_t flags) {
+	if (!s || !cam || (n_tiles && !tiles) || !accum_rgb || !samples) return fail(PTX_ERR_INVALID, "ptx_render_tiles: null argument");
+	if (s->rec.mesh_only) return fail(PTX_ERR_INVALID, "ptx_render_tiles: the scene was created with ptx_scene_create_mesh and has no materials");
+	if (!cam->film_width || !cam->film_height) return fail(PTX_ERR_INVALID, "ptx_render_tiles: empty film");
+	for (uint32_t i = 0; i < n_tiles; i++) {
+		const PtxTile& t = tiles[i];
+		if (t.x_begin > t.x_end || t.y_begin > t.y_end || t.s_begin > t.s_end || t.x_end > cam->film_width || t.y_end > cam->film_height)
+			return fail(PTX_ERR_INVALID, "ptx_render_tiles: tile outside the film or with reversed bounds");
+	}
+	if (n_tiles == 0) return PTX_OK;
+	PTX_HIP(hipSetDevice(s->device));
+	const size_t n_pixels = size_t(cam->film_width) * cam->film_height;
+	const bool host = !(flags & PTX_MEM_DEVICE);
+	unsigned long long* d_accum = reinterpret_cast<unsigned long long*>(accum_rgb);
+	uint32_t* d_samples = samples;
+	if (host) {
+		void *a = nullptr, *b = nullptr;
+		if (int rc = device_alloc(s, 0, n_pixels * 3 * sizeof(int64_t), &a)) return rc;
+		if (int rc = device_alloc(s, 1, n_pixels * sizeof(uint32_t), &b)) return rc;
+		d_accum = static_cast<unsigned long long*>(a), d_samples = static_cast<uint32_t*>(b);
+		PTX_HIP(hipMemcpyAsync(d_accum, accum_rgb, n_pixels * 3 * sizeof(int64_t), hipMemcpyHostToDevice, s->stream));
+		PTX_HIP(hipMemcpyAsync(d_samples, samples, n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+	}
+
+	CameraRec cr{};
+	cr.h = 2.0f * std::tan((cam->vertical_fov / 2.0f) * (3.14159265358979323846264338327950288f / 180.0f));   // camera.cpp:30
+	cr.w = cam->aspect_ratio * cr.h;
+	cr.film_w = cam->film_width, cr.film_h = cam->film_height, cr.max_depth = cam->film_max_ray_depth;
+	std::copy(cam->camera_to_world, cam->camera_to_world + 16, cr.cam_to_world);
+	const uint32_t key0 = uint32_t(seed), key1 = uint32_t(seed >> 32);
+
+	// Tiles are processed in chunks whose slots fit the state buffers.
+	uint32_t next_tile = 0;
+	while (next_tile < n_tiles) {
+		std::vector<TileRec> chunk;
+		uint64_t n_slots = 0;
+		uint32_t max_samples = 0;
+		while (next_tile < n_tiles) {
+			const PtxTile& t = tiles[next_tile];
+			const uint64_t px = uint64_t(t.x_end - t.x_begin) * (t.y_end - t.y_begin);
+			if (!chunk.empty() && n_slots + px > MAX_SLOTS_PER_CHUNK) break;
+			if (px > 0xFFFFFFFFull - n_slots) return fail(PTX_ERR_UNSUPPORTED, "ptx_render_tiles: a single tile larger than 2^32 pixels");
+			if (px && t.s_end > t.s_begin) {
+				chunk.push_back(TileRec{t.x_begin, t.y_begin, t.x_end - t.x_begin, t.y_end - t.y_begin, t.s_begin, t.s_end - t.s_begin, uint32_t(n_slots), 0});
+				n_slots += px;
+				max_samples = std::max(max_samples, t.s_end - t.s_begin);
+			}
+			next_tile++;
+		}
+		if (chunk.empty()) continue;
+		const uint32_t ns = uint32_t(n_slots);
+		RenderBuffers rb{};
+		void* p = nullptr;
+		if (int rc = device_alloc(s, 2, chunk.size() * sizeof(TileRec), &p)) return rc;
+		TileRec* d_tiles = static_cast<TileRec*>(p);
+		// one allocation for all per-slot state
+		const size_t bytes = n_slots * (sizeof(SlotInfo) + sizeof(float4) + sizeof(PathState) + 2 * sizeof(PtxRay) + 2 * sizeof(HitRec) + 2 * sizeof(uint32_t)) + 256;
+		if (int rc = device_alloc(s, 3, bytes, &p)) return rc;
+		char* base = static_cast<char*>(p);
+		rb.counts = reinterpret_cast<uint32_t*>(base), base += 256;
+		rb.hits = reinterpret_cast<HitRec*>(base), base += n_slots * 2 * sizeof(HitRec);
+		rb.rays = reinterpret_cast<PtxRay*>(base), base += n_slots * 2 * sizeof(PtxRay);
+		rb.paths = reinterpret_cast<PathState*>(base), base += n_slots * sizeof(PathState);
+		rb.sums = reinterpret_cast<float4*>(base), base += n_slots * sizeof(float4);
+		rb.slots = reinterpret_cast<SlotInfo*>(base), base += n_slots * sizeof(SlotInfo);
+		rb.active[0] = reinterpret_cast<uint32_t*>(base), base += n_slots * sizeof(uint32_t);
+		rb.active[1] = reinterpret_cast<uint32_t*>(base);
+		PTX_HIP(hipMemcpyAsync(d_tiles, chunk.data(), chunk.size() * sizeof(TileRec), hipMemcpyHostToDevice, s->stream));
+		hipLaunchKernelGGL(k_init_slots, dim3(uint32_t(chunk.size())), dim3(256), 0, s->stream, d_tiles, cam->film_width, rb);
+
+		const dim3 block(256), grid_slots((ns + 255) / 256), grid_items((2 * uint64_t(ns) + 255) / 256);
+		for (uint32_t k = 0; k < max_samples; k++) {
+			PTX_HIP(hipMemsetAsync(rb.counts, 0, 256, s->stream));
+			hipLaunchKernelGGL(k_raygen, grid_slots, block, 0, s->stream, rb, ns, k, cr, key0, key1, rb.active[0], rb.counts + 0);
+			int cur = 0;
+			// A camera ray of depth D has at most D+1 vertices on its main path (depths D..0): the
+			// vertex of depth 0 never scatters, so after D+1 rounds no path is alive and every
+			// direct ray (written in round r, used at the start of round r+1) has been consumed.
+			for (uint32_t round = 0; round <= cam->film_max_ray_depth; round++) {
+				hipLaunchKernelGGL(k_extend<MODE_CULLED>, grid_items, block, 0, s->stream, s->rec, rb, rb.active[cur], rb.counts + cur);
+				PTX_HIP(hipMemsetAsync(rb.counts + (cur ^ 1), 0, sizeof(uint32_t), s->stream));
+				hipLaunchKernelGGL(k_shade<MODE_CULLED>, grid_slots, block, 0, s->stream, s->rec, s->shade, rb, rb.active[cur], rb.counts + cur, key0, key1,
+				                   rb.active[cur ^ 1], rb.counts + (cur ^ 1));
+				cur ^= 1;
+			}
+		}
+		hipLaunchKernelGGL(k_flush, grid_slots, block, 0, s->stream, rb, ns, d_accum, d_samples);
+		PTX_HIP(hipGetLastError());
+		for (const TileRec& t : chunk) s->counters.paths += uint64_t(t.w) * t.h * t.s_count;
+	}
+	if (host) {
+		PTX_HIP(hipMemcpyAsync(accum_rgb, d_accum, n_pixels * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+		PTX_HIP(hipMemcpyAsync(samples, d_samples, n_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+	}
+	if (!(flags & PTX_ASYNC) || host) PTX_HIP(hipStreamSynchronize(s->stream));
+	return PTX_OK;
 }

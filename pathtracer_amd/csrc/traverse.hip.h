@@ -386,6 +386,7 @@ __device__ __forceinline__ bool sphere_test(float radius, const Ray3& r, float& 
 struct SceneHit {
 	bool hit;
 	float distance;    // world-space Trace::distance
+	float t;           // ray parameter in the hit instance's object space
 	uint32_t prim, inst;
 	float u, v;
 };
@@ -417,7 +418,7 @@ __device__ __forceinline__ bool instance_hit(const SceneRec& sc, uint32_t inst_i
 		mat_point(in.T, r.ox, r.oy, r.oz, qx, qy, qz);
 		dist = norm3(wx - qx, wy - qy, wz - qz);
 	}
-	out.hit = true, out.distance = dist, out.prim = prim, out.inst = inst_index, out.u = u, out.v = v;
+	out.hit = true, out.distance = dist, out.t = t, out.prim = prim, out.inst = inst_index, out.u = u, out.v = v;
 	return true;
 }
 
@@ -430,7 +431,7 @@ __device__ __forceinline__ void traverse_scene(const SceneRec& sc, const Ray3& r
 	if (MESH_ONLY || sc.mesh_only) {
 		MeshHit mh;
 		traverse_mesh<MODE, ANY, STATS>(sc, sc.meshes[0], r, st, 0, mh, stats);
-		cur.hit = mh.hit, cur.distance = mh.distance, cur.prim = mh.prim, cur.inst = 0, cur.u = mh.u, cur.v = mh.v;
+		cur.hit = mh.hit, cur.distance = mh.distance, cur.t = mh.t, cur.prim = mh.prim, cur.inst = 0, cur.u = mh.u, cur.v = mh.v;
 		return;
 	}
 	if (MESH_ONLY) return;

@@ -1,0 +1,164 @@
+"""ptx_render_tiles (the Pathtracer::do_trace / trace / accumulate path, pathtracer.cpp:126-173, 407-477)
+against the CPU checker.
+
+Two comparisons:
+  * same counter-based random stream on both sides: every path takes the same decisions, so the
+    images agree to float rounding (device sin/cos/atan2/acos/pow may differ from libm in the last
+    bit, and the device sums radiance front-to-back where the recursion sums back-to-front).
+    Tolerance: per-pixel relative difference <= 1e-3 on >= 99.5 % of the pixels (a last-bit
+    difference can flip a Fresnel coin or a hit and send one sample down another path) and
+    RMSE <= 1e-3 * mean.
+  * the checker with the reference's own mt19937-per-tile stream: a different sample set of the same
+    estimator, so the images agree statistically; tolerance: RMSE <= 4x the RMSE between two
+    independent checker renders.
+"""
+import numpy as np
+import pytest
+
+from pathtracer_amd import abi, capi
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0xABCDEF12345
+
+
+def camera(w, h, spp, depth, pos=(0, 0, 3.4), axis=(0, 1, 0), deg=0.0, fov=60.0):
+    cam = abi.PtxCamera()
+    cam.vertical_fov, cam.aspect_ratio = fov, w / h
+    cam.film_width, cam.film_height, cam.film_samples, cam.film_max_ray_depth = w, h, spp, depth
+    T = scenes.trs(pos, axis=axis, deg=deg)
+    for i in range(16):
+        cam.camera_to_world[i] = float(T[i])
+    return cam
+
+
+def lit_scene(kind, **kw):
+    sb = scenes.instanced_scene(**kw)
+    if kind in ("delta", "all"):
+        sb.add_delta_light(abi.PTX_LIGHT_POINT, (1, 0.9, 0.8), 2.0, scenes.trs((0.5, 0.5, 0.5)))
+        sb.add_delta_light(abi.PTX_LIGHT_SPOT, (0.3, 0.9, 0.8), 3.0, scenes.trs((-0.5, 0.9, 0.5), axis=(1, 0, 0), deg=20), 40.0, 70.0)
+        sb.add_delta_light(abi.PTX_LIGHT_DIRECTIONAL, (0.5, 0.5, 1.0), 0.7, scenes.trs(axis=(0, 0, 1), deg=35))
+    if kind in ("env", "all"):
+        g = np.random.Generator(np.random.Philox(key=5))
+        img = g.random((16, 32, 3), dtype=np.float32)
+        sb.add_env_light(abi.PTX_ENV_SPHERE, sb.add_image_texture(img, abi.PTX_SAMPLER_BILINEAR))
+        sb.add_env_light(abi.PTX_ENV_HEMISPHERE, sb.add_constant_texture((0.2, 0.3, 0.5)))
+    return sb
+
+
+def images(oracle, sb, cam, tiles):
+    desc = sb.desc()
+    osc = oracle.scene(desc)
+    gsc = capi.Scene(desc, keep=sb)
+    try:
+        acc_o, smp_o = osc.render_tiles(cam, tiles, 1, SEED)
+        acc_g, smp_g = gsc.render_tiles(cam, tiles, SEED)
+    finally:
+        osc.close()
+        gsc.close()
+    assert (smp_o == smp_g).all()
+    return capi.accumulator_to_image(acc_o, smp_o), capi.accumulator_to_image(acc_g, smp_g)
+
+
+def assert_same_stream(io, ig):
+    d = np.abs(io - ig)
+    rel = (d / np.maximum(np.abs(io), 1e-3)).max(axis=1)
+    assert (rel <= 1e-3).mean() >= 0.995, f"{(rel > 1e-3).mean():.4f} of the pixels differ"
+    assert np.sqrt((d ** 2).mean()) <= 1e-3 * max(io.mean(), 1e-6)
+
+
+@pytest.mark.parametrize("kind,use_bvh,fresnel", [
+    ("delta", True, abi.PTX_FRESNEL_GCC_INT_ABS),
+    ("delta", True, abi.PTX_FRESNEL_FLOAT_ABS),
+    ("env", True, abi.PTX_FRESNEL_GCC_INT_ABS),
+    ("all", False, abi.PTX_FRESNEL_FLOAT_ABS),
+    ("none", True, abi.PTX_FRESNEL_GCC_INT_ABS),
+])
+def test_render_same_stream(oracle, kind, use_bvh, fresnel):
+    sb = lit_scene(kind, use_bvh=use_bvh, mesh_bvh=use_bvh, fresnel_mode=fresnel)
+    w, h, spp = 120, 72, 6
+    cam = camera(w, h, spp, 4)
+    tiles = capi.make_tiles(w, h, spp, 77)
+    io, ig = images(oracle, sb, cam, tiles)
+    assert io.mean() > 0.01
+    assert_same_stream(io, ig)
+
+
+def test_render_open_scene_camera_inside_env(oracle):
+    """No room: most camera rays leave the scene and pick up the environment."""
+    sb = abi.SceneBuilder()
+    g = np.random.Generator(np.random.Philox(key=6))
+    env = sb.add_image_texture(g.random((8, 16, 3), dtype=np.float32), abi.PTX_SAMPLER_NEAREST)
+    sb.add_env_light(abi.PTX_ENV_SPHERE, env)
+    tex = sb.add_image_texture(g.random((32, 32, 3), dtype=np.float32), abi.PTX_SAMPLER_BILINEAR)
+    ico = sb.add_mesh(*scenes.icosphere(3))
+    sb.add_instance(ico, sb.add_material(abi.PTX_MAT_LAMBERTIAN, tex), scenes.trs((0, 0, 0), axis=(1, 1, 0), deg=40, scale=(1.0, 0.7, 1.2)))
+    sb.add_instance(-1, sb.add_material(abi.PTX_MAT_GLASS, env, tex, 1.45), scenes.trs((1.6, 0.2, 0.4), scale=(0.6, 0.6, 0.6)), sphere_radius=1.0)
+    w, h, spp = 96, 96, 4
+    cam = camera(w, h, spp, 6, pos=(0.8, 0.6, 4.0), axis=(1, 0, 0), deg=-8, fov=45.0)
+    io, ig = images(oracle, sb, cam, capi.make_tiles(w, h, spp, 3))
+    assert_same_stream(io, ig)
+
+
+def test_render_depth_zero_and_overlapping_tiles(oracle):
+    """max depth 0 shows emission only; tiles that share pixels and split the sample range add up."""
+    sb = lit_scene("delta")
+    w, h = 64, 48
+    cam = camera(w, h, 8, 0)
+    tiles = np.zeros(4, dtype=abi.TILE_DTYPE)
+    tiles[0] = (1, 0, 64, 0, 48, 0, 3)
+    tiles[1] = (2, 10, 50, 5, 40, 3, 8)     # more samples for an inner window
+    tiles[2] = (3, 0, 64, 0, 48, 3, 3)      # empty sample range: nothing
+    tiles[3] = (4, 20, 20, 0, 48, 0, 8)     # empty pixel range: nothing
+    io, ig = images(oracle, sb, cam, tiles)
+    assert_same_stream(io, ig)
+    cam4 = camera(w, h, 8, 3)
+    io, ig = images(oracle, sb, cam4, tiles)
+    assert_same_stream(io, ig)
+
+
+def test_render_matches_reference_stream_statistically(oracle):
+    """Against the checker driven by mt19937 per tile (what the reference does): same estimator, other samples."""
+    sb = lit_scene("delta")
+    desc = sb.desc()
+    w, h, spp = 80, 60, 64
+    cam = camera(w, h, spp, 4)
+    tiles_a = capi.make_tiles(w, h, spp, 11)
+    tiles_b = capi.make_tiles(w, h, spp, 12)
+    osc = oracle.scene(desc)
+    gsc = capi.Scene(desc, keep=sb)
+    try:
+        ia = capi.accumulator_to_image(*osc.render_tiles(cam, tiles_a, 0, 0))
+        ib = capi.accumulator_to_image(*osc.render_tiles(cam, tiles_b, 0, 0))
+        ig = capi.accumulator_to_image(*gsc.render_tiles(cam, tiles_a, SEED))
+    finally:
+        osc.close()
+        gsc.close()
+    noise = np.sqrt(((ia - ib) ** 2).mean())
+    assert np.sqrt(((ig - ia) ** 2).mean()) <= 4 * noise
+    assert abs(ig.mean() - ia.mean()) <= 0.05 * ia.mean()
+    # tone-mapped 8-bit output of both, as the reference writes it
+    ta, tg = capi.tonemap(ia, 1.0), capi.tonemap(ig, 1.0)
+    assert abs(ta[:, :3].astype(np.float64).mean() - tg[:, :3].astype(np.float64).mean()) <= 3.0
+
+
+def test_render_device_accumulator_and_errors():
+    torch = pytest.importorskip("torch")
+    sb = lit_scene("delta")
+    w, h, spp = 64, 64, 4
+    cam = camera(w, h, spp, 3)
+    tiles = capi.make_tiles(w, h, spp, 5)
+    gsc = capi.Scene(sb.desc(), keep=sb)
+    acc_h, smp_h = gsc.render_tiles(cam, tiles, SEED)
+    acc_d = torch.zeros(w * h * 3, dtype=torch.int64, device="cuda")
+    smp_d = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    gsc.render_tiles(cam, tiles, SEED, acc_d, smp_d)
+    torch.cuda.synchronize()
+    assert (acc_d.cpu().numpy() == acc_h).all()          # same stream, same arithmetic: bit-identical
+    assert (smp_d.cpu().numpy().astype(np.uint32) == smp_h).all()
+    bad = tiles.copy()
+    bad["x_end"][0] = w + 1
+    with pytest.raises(capi.PtxError):
+        gsc.render_tiles(cam, bad, SEED)
+    gsc.close()

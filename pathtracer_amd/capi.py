@@ -28,6 +28,14 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise PtxError(f"{LIB_PATH} is missing: build it with `make -C pathtracer_amd/csrc` (there is no CPU fallback)")
+    # One HIP/HSA runtime per process: torch ships its own copy of the ROCm runtime libraries, and a
+    # process that loads the system copy first and torch's second ends up with two HSA runtimes,
+    # the second of which sees no GPU.  Loading torch first (when it is installed) makes this
+    # library resolve its libamdhip64 dependency to the copy torch already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.ptx_last_error.restype = C.c_char_p
     L.ptx_version.restype = C.c_char_p

@@ -1,0 +1,201 @@
+"""Generates the committed golden vectors under tests/golden/ from the reference's own code.
+
+Runs only in the development container, where oracle/_ref/libptref.so (the reference's
+translation units compiled by oracle/Makefile) exists.  Every fixture is data: seeded inputs
+(or their generator parameters) and the outputs the reference computed for them.
+
+    python tests/golden/make_golden.py
+
+Fixtures (all little-endian numpy .npz):
+  hits_fuzz462.npz     first trial of the reference's fuzz generator (RNG(462)): vertex positions,
+                       4096 rays, and Tri_Mesh::hit results through the reference's BVH builder
+  hits_sphere3.npz     Util::sphere_mesh(1, 3): vertices, indices, 4096 rays, results
+  hits_soup20k.npz     synth.soup(20000): results of the reference's BVH::hit over a tree built by
+                       this repo's builder and injected through the public nodes/primitives members
+  scene_hits.npz       tests/scenes.instanced_scene(): Aggregate(BVH<Instance>)::hit and List results
+  builder.npz          node arrays of the reference builder (digest + head) for the meshes above
+  probes.npz           BBox::hit, Triangle::hit, Sphere::hit, Mat4::inverse, rotate_to, RNG::unit,
+                       Materials::*::scatter on seeded inputs
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+from pathtracer_amd import abi, capi, synth  # noqa: E402
+import scenes  # noqa: E402
+from _oracle import Ref  # noqa: E402
+
+N_RAYS = 4096
+
+
+def digest(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def mesh_rays(verts, n, seed):
+    """Rays aimed into the mesh's bounding box from around it (about half of them hit something)."""
+    g = np.random.Generator(np.random.Philox(key=seed))
+    lo, hi = verts[:, :3].min(axis=0), verts[:, :3].max(axis=0)
+    c, e = (lo + hi) / 2, (hi - lo)
+    o = c + (g.random((n, 3)) * 2 - 1) * e * 1.2
+    t = lo + g.random((n, 3)) * e
+    d = t - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.zeros(n, dtype=abi.RAY_DTYPE)
+    r["o"] = o.astype(np.float32)
+    r["d"] = synth._unit_f32(d)
+    r["tmin"], r["tmax"] = 0.0, np.inf
+    # a quarter of the rays get finite bounds, as shadow rays have
+    r["tmin"][::4] = 1e-5
+    r["tmax"][::4] = (g.random(len(r["tmax"][::4])) * np.linalg.norm(e)).astype(np.float32)
+    return r
+
+
+def hit_fields(res):
+    h = res["hits"]
+    return dict(distance_bits=h["distance"].view(np.uint32), prim=h["prim"], pos=res["pos"], normal=res["normal"], uv=res["uv"])
+
+
+def main():
+    ref = Ref()
+    out = {}
+
+    # ---- fuzz mesh
+    verts, idx, _ = ref.fuzz_mesh(462, 1)
+    rays = mesh_rays(verts, N_RAYS, 1001)
+    m = ref.mesh(verts, idx, use_bvh=True)
+    nodes_fuzz = m.nodes()
+    np.savez_compressed(os.path.join(HERE, "hits_fuzz462.npz"), positions=verts[:, :3].copy(), rays=rays.view(np.float32).reshape(-1, 8),
+                        **hit_fields(m.hit(rays, full=True)))
+    out["fuzz462_nodes_sha256"], out["fuzz462_nodes_head"], out["fuzz462_n_nodes"] = digest(nodes_fuzz), nodes_fuzz[:64], len(nodes_fuzz)
+    out["fuzz462_prim_boxes_sha256"] = digest(m.prim_boxes())
+    m.close()
+
+    # ---- sphere mesh
+    verts, idx = ref.sphere_mesh(1.0, 3)
+    rays = mesh_rays(verts, N_RAYS, 1002)
+    m = ref.mesh(verts, idx, use_bvh=True, id_coded=False)      # real normals / uvs
+    full = m.hit(rays, full=True)
+    m.close()
+    m = ref.mesh(verts, idx, use_bvh=True, id_coded=True)       # triangle ids
+    ids = m.hit(rays, full=True)
+    nodes_sphere = m.nodes()
+    m.close()
+    f = hit_fields(ids)
+    f["normal"], f["uv"] = full["normal"], full["uv"]
+    np.savez_compressed(os.path.join(HERE, "hits_sphere3.npz"), verts=verts, indices=idx, rays=rays.view(np.float32).reshape(-1, 8), **f)
+    out["sphere3_nodes_sha256"], out["sphere3_nodes_head"], out["sphere3_n_nodes"] = digest(nodes_sphere), nodes_sphere[:64], len(nodes_sphere)
+    ml = ref.mesh(verts, idx, use_bvh=False)
+    lst = ml.hit(rays, full=True)
+    ml.close()
+    np.savez_compressed(os.path.join(HERE, "hits_sphere3_list.npz"), **hit_fields(lst))
+
+    # ---- soup with this repo's tree injected into the reference's BVH
+    verts, idx = synth.soup(20000)
+    bvh = capi.Bvh(verts=verts, indices=idx, max_leaf_size=4)
+    nodes, order = bvh.nodes(), bvh.order()
+    rays = synth.rays(N_RAYS)
+    m = ref.mesh(verts, idx[order], use_bvh=True, nodes=nodes)
+    res = m.hit(rays, full=True)
+    m.close()
+    f = hit_fields(res)
+    hit = f["prim"] != abi.PTX_NO_HIT
+    f["prim"] = np.where(hit, order[np.minimum(f["prim"], len(order) - 1)], abi.PTX_NO_HIT).astype(np.uint32)   # ids in input order
+    np.savez_compressed(os.path.join(HERE, "hits_soup20k.npz"), **f)
+    # the reference's own builder on the same soup: node array digest
+    m = ref.mesh(verts, idx, use_bvh=True)
+    n20 = m.nodes()
+    out["soup20k_nodes_sha256"], out["soup20k_nodes_head"], out["soup20k_n_nodes"] = digest(n20), n20[:64], len(n20)
+    m.close()
+
+    # ---- instanced scene through Aggregate / Instance / Trace::transform
+    for name, use_bvh in (("bvh", True), ("list", False)):
+        sb = scenes.instanced_scene(use_bvh=use_bvh, mesh_bvh=use_bvh)
+        sc = ref.scene(sb.desc())
+        rays = scenes.scene_rays(N_RAYS)
+        r = sc.hit(rays)
+        sc.close()
+        np.savez_compressed(os.path.join(HERE, f"scene_hits_{name}.npz"), hit=r["hit"], distance_bits=r["distance"].view(np.uint32), pos=r["pos"],
+                            normal=r["normal"], uv=r["uv"], material=r["material"])
+
+    np.savez_compressed(os.path.join(HERE, "builder.npz"), **out)
+
+    # ---- probes on seeded inputs
+    g = np.random.Generator(np.random.Philox(key=2024))
+    p = {}
+    n = 2048
+    boxes = np.sort(g.random((n, 2, 3), dtype=np.float32) * 4 - 2, axis=1).reshape(n, 6)
+    brays = scenes.scene_rays(n, seed=11, extent=3.0, inside=False)
+    brays["d"][::7, 0] = 0.0          # axis-parallel directions reach the divide-by-zero branches
+    brays["d"][::11, 1] = 0.0
+    brays["o"][::13] = boxes[::13, :3]  # origins on a box face: 0/0 cases
+    bh = np.zeros(n, dtype=np.uint8)
+    bt = np.zeros((n, 2), dtype=np.float32)
+    for i in range(n):
+        h, t = ref.bbox_hit(boxes[i], brays[i:i + 1], (0.0, np.inf))
+        bh[i], bt[i] = h, t
+    p.update(bbox_boxes=boxes, bbox_rays=brays.view(np.float32).reshape(-1, 8), bbox_hit=bh, bbox_times_bits=bt.view(np.uint32))
+
+    tv = np.zeros((n, 3, 8), dtype=np.float32)
+    tv[:, :, :3] = g.random((n, 3, 3), dtype=np.float32) * 2 - 1
+    tv[:, :, 3:6] = g.standard_normal((n, 3, 3)).astype(np.float32)
+    tv[:, :, 6:] = g.random((n, 3, 2), dtype=np.float32)
+    trays = scenes.scene_rays(n, seed=12, extent=1.0)
+    th = np.zeros(n, dtype=np.uint8)
+    tout = np.zeros((n, 12), dtype=np.float32)
+    tb = np.zeros((n, 6), dtype=np.float32)
+    for i in range(n):
+        h, o = ref.triangle_hit(tv[i], trays[i:i + 1])
+        th[i], tout[i] = h, o
+        tb[i] = ref.triangle_bbox(tv[i])
+    p.update(tri_verts=tv, tri_rays=trays.view(np.float32).reshape(-1, 8), tri_hit=th, tri_out_bits=tout.view(np.uint32), tri_bbox_bits=tb.view(np.uint32))
+
+    srays = scenes.scene_rays(n, seed=13, extent=2.0, inside=False)
+    sr = (g.random(n, dtype=np.float32) * 1.5 + 0.25)
+    sh = np.zeros(n, dtype=np.uint8)
+    so = np.zeros((n, 9), dtype=np.float32)
+    for i in range(n):
+        h, o = ref.sphere_hit(float(sr[i]), srays[i:i + 1])
+        sh[i], so[i] = h, o
+    p.update(sphere_radius=sr, sphere_rays=srays.view(np.float32).reshape(-1, 8), sphere_hit=sh, sphere_out=so)
+
+    mats = np.stack([scenes.trs(g.random(3) * 4 - 2, g.standard_normal(3), float(g.random() * 360), g.random(3) * 2 + 0.1) for _ in range(256)])
+    p.update(mat4_in=mats, mat4_inverse_bits=np.stack([ref.mat4_inverse(m) for m in mats]).view(np.uint32))
+    dirs = g.standard_normal((256, 3)).astype(np.float32)
+    dirs[0], dirs[1] = (0, 1, 0), (0, -1, 0)
+    p.update(rotate_to_in=dirs, rotate_to_bits=np.stack([ref.rotate_to(d) for d in dirs]).view(np.uint32))
+    p.update(rng_seed=np.array([1, 462, 4660], dtype=np.uint32), rng_units_bits=np.stack([ref.rng_units(s, 64) for s in (1, 462, 4660)]).view(np.uint32))
+
+    outs = g.standard_normal((512, 3))
+    outs /= np.linalg.norm(outs, axis=1, keepdims=True)
+    outs = outs.astype(np.float32)
+    ca, cb = (0.9, 0.6, 0.3), (0.25, 0.5, 0.75)
+    for name, mt, ior in (("lambertian", abi.PTX_MAT_LAMBERTIAN, 1.5), ("mirror", abi.PTX_MAT_MIRROR, 1.5), ("refract", abi.PTX_MAT_REFRACT, 1.33),
+                          ("glass", abi.PTX_MAT_GLASS, 1.5), ("glass_ior1", abi.PTX_MAT_GLASS, 1.0)):
+        p[f"scatter_{name}"] = ref.material_scatter(mt, ca, cb, ior, 462, outs)
+    p.update(scatter_out_dirs=outs)
+
+    edirs = g.standard_normal((512, 3))
+    edirs /= np.linalg.norm(edirs, axis=1, keepdims=True)
+    # The reference's bilinear sampler indexes one texel past the image for lookups within half a
+    # texel of its border (an assert in HDR_Image::at stops the process there): keep interior lookups.
+    eu = np.arctan2(edirs[:, 2], edirs[:, 0]) / (2 * np.pi)
+    eu = np.where(eu < 0, eu + 1, eu) * 12
+    ev = np.arccos(-edirs[:, 1]) / np.pi * 6
+    edirs = edirs[(eu > 0.75) & (eu < 11.25) & (ev > 0.75) & (ev < 5.25)]
+    img = g.random((6, 12, 3), dtype=np.float32)
+    p.update(env_image=img, env_dirs=edirs.astype(np.float32), env_bilinear=ref.env_sphere_evaluate(img, abi.PTX_SAMPLER_BILINEAR, edirs),
+             env_nearest=ref.env_sphere_evaluate(img, abi.PTX_SAMPLER_NEAREST, edirs))
+    np.savez_compressed(os.path.join(HERE, "probes.npz"), **p)
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

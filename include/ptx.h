@@ -96,9 +96,12 @@ typedef struct PtxBvhNode {
 typedef struct PtxBvh* ptx_bvh_t;
 
 /* Builds the binned-SAH tree over boxes (n x 6 floats: min xyz, max xyz), 8 bins per axis,
- * exactly as BVH::build/buildRecursive do, with the bin index clamped to [0,7] and the
- * partition taken from the bin index (the reference indexes bins[] out of range and lets
- * ranges and boxes disagree on large inputs).  max_leaf_size: 4 for triangles
+ * exactly as BVH::build/buildRecursive do (bvh.cpp:31-243): child sizes and boxes from the bin
+ * counts, primitives partitioned by the reference's separately evaluated predicate -- so the
+ * node array equals the reference's byte for byte.  One guard: the bin index is clamped to
+ * [0,7] where the reference would index bins[] out of range.  ptx_bvh_get_stats reports how
+ * often the clamp applied, how often predicate and bin disagreed, and primitives dropped by the
+ * reference's "no split separates" branch.  max_leaf_size: 4 for triangles
  * (tri_mesh.cpp:173), 1 for instances (bvh.h:26). */
 int ptx_bvh_build(const float* boxes, uint32_t n, uint32_t max_leaf_size, ptx_bvh_t* out);
 /* Convenience: boxes are Triangle::bbox (tri_mesh.cpp:10-44) of an indexed mesh whose
@@ -274,6 +277,34 @@ typedef struct PtxCounters {
 	uint64_t paths;          /* camera samples traced by ptx_render_tiles */
 } PtxCounters;
 int ptx_get_counters(ptx_scene_t scene, PtxCounters* out);
+
+/* ------------------------------------------------------------------ scene files and image output */
+/* The reference's JSON scene format ("js3d-v1"): load(filepath, &scene, &animator)
+ * (scene/io.cpp:15-70, scene/load-save-json.cpp:108-333) followed by what Pathtracer::build_scene
+ * (pathtracer.cpp:182-387) derives from a Scene: half-edge meshes flattened with
+ * Indexed_Mesh::from_halfedge_mesh(..., SplitEdges) (geometry/indexed.cpp:10-34), one instance per
+ * visible mesh / shape instance with its Transform::local_to_world() (scene/transform.cpp:12-24),
+ * materials, textures, delta-light instances and every environment light.  Names are visited in
+ * sorted order.  Skinned meshes, particles and the binary .s3d format are not read (a warning is
+ * recorded).  The handle owns every array the returned PtxSceneDesc points to. */
+typedef struct PtxJs3d* ptx_js3d_t;
+int ptx_js3d_load(const char* path, ptx_js3d_t* out);
+void ptx_js3d_free(ptx_js3d_t s);
+const PtxSceneDesc* ptx_js3d_scene_desc(ptx_js3d_t s);
+/* Pathtracer::use_bvh (pathtracer.h:37: meshes and the instance level alike) and the Fresnel mode. */
+void ptx_js3d_set_modes(ptx_js3d_t s, uint32_t use_bvh, uint32_t fresnel_mode);
+/* Camera instances (scene.instances.cameras, main.cpp:125-136): film and lens values of the
+ * camera resource, camera_to_world = the instance transform's local_to_world(). */
+uint32_t ptx_js3d_num_cameras(ptx_js3d_t s);
+const char* ptx_js3d_camera_name(ptx_js3d_t s, uint32_t i);
+int ptx_js3d_get_camera(ptx_js3d_t s, const char* name, PtxCamera* out);
+uint32_t ptx_js3d_num_meshes(ptx_js3d_t s);
+const char* ptx_js3d_mesh_name(ptx_js3d_t s, uint32_t i);
+const char* ptx_js3d_instance_name(ptx_js3d_t s, uint32_t i);
+const char* ptx_js3d_warnings(ptx_js3d_t s);
+/* stbi_write_png with stbi_flip_vertically_on_write(true) (main.cpp:339-343): 8-bit RGBA, image
+ * row 0 is the bottom row (util/hdr_image.h:13) and is written last when flip_rows is non-zero. */
+int ptx_write_png(const char* path, const uint8_t* rgba, uint32_t width, uint32_t height, int flip_rows);
 
 #ifdef __cplusplus
 }

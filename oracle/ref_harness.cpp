@@ -23,12 +23,18 @@
 #include "scene/shape.h"
 #include "scene/texture.h"
 #include "util/rand.h"
+#include "scene/io.h"
+#include "scene/scene.h"
+#include "scene/animator.h"
 
 #include "../include/ptx.h"
 
 #include <atomic>
 #include <cstring>
+#include <algorithm>
+#include <map>
 #include <memory>
+#include <string>
 #include <thread>
 
 namespace {
@@ -375,6 +381,89 @@ void ref_ray_make(const float* o3, const float* d3, const float* T16, PtxRay* ou
 	Ray r(Vec3(o3[0], o3[1], o3[2]), Vec3(d3[0], d3[1], d3[2]));
 	if (T16) r.transform(mat_from(T16));
 	*out = PtxRay{{r.point.x, r.point.y, r.point.z}, {r.dir.x, r.dir.y, r.dir.z}, r.dist_bounds.x, r.dist_bounds.y};
+}
+
+// ---- scene files: the reference's own loader (scene/io.cpp:15-70) and mesh flattening
+// (Indexed_Mesh::from_halfedge_mesh(..., SplitEdges), geometry/indexed.cpp:10-34; Transform::local_to_world,
+// scene/transform.cpp:4-24), serialised to a flat byte stream:
+//   u32 n_meshes        { str name, u32 n_verts, u32 n_indices, f32 verts[n_verts*8] (pos, normal, uv), u32 indices[] }
+//   u32 n_mesh_insts    { str name, str mesh, str material ("" = none), u32 visible, f32 T[16] }
+//   u32 n_shape_insts   { str name, f32 radius, str material, u32 visible, f32 T[16] }
+//   u32 n_camera_insts  { str name, f32 T[16], f32 vfov, f32 aspect, u32 w, u32 h, u32 samples, u32 depth }
+//   u32 n_light_insts   { str name, u32 type (0 point, 1 directional, 2 spot), f32 color[3], f32 intensity, f32 inner, f32 outer, u32 visible, f32 T[16] }
+// str = u32 length + bytes.  Names in sorted order.  Returns the stream's size; writes it if it fits `cap`.
+uint64_t ref_js3d_flatten(const char* path, uint8_t* out, uint64_t cap) {
+	Scene scene;
+	Animator animator;
+	try {
+		load(path, &scene, &animator);
+	} catch (std::exception const&) {
+		return 0;
+	}
+	std::vector<uint8_t> buf;
+	auto put = [&](const void* p, size_t n) { buf.insert(buf.end(), static_cast<const uint8_t*>(p), static_cast<const uint8_t*>(p) + n); };
+	auto u32 = [&](uint32_t v) { put(&v, 4); };
+	auto f32 = [&](float v) { put(&v, 4); };
+	auto str = [&](const std::string& v) { u32(uint32_t(v.size())), put(v.data(), v.size()); };
+	auto mat = [&](const Mat4& m) { for (int c = 0; c < 4; c++) for (int k = 0; k < 4; k++) f32(m[c][k]); };
+	auto sorted = [](auto const& storage) {
+		std::vector<std::string> names;
+		for (auto const& kv : storage) names.push_back(kv.first);
+		std::sort(names.begin(), names.end());
+		return names;
+	};
+	u32(uint32_t(scene.meshes.size()));
+	for (auto const& name : sorted(scene.meshes)) {
+		Indexed_Mesh im = Indexed_Mesh::from_halfedge_mesh(*scene.meshes.at(name), Indexed_Mesh::SplitEdges);
+		str(name), u32(uint32_t(im.vertices().size())), u32(uint32_t(im.indices().size()));
+		for (auto const& v : im.vertices()) f32(v.pos.x), f32(v.pos.y), f32(v.pos.z), f32(v.norm.x), f32(v.norm.y), f32(v.norm.z), f32(v.uv.x), f32(v.uv.y);
+		for (auto i : im.indices()) u32(i);
+	}
+	auto name_of = [&](auto const& storage, auto const& weak) -> std::string {
+		auto sp = weak.lock();
+		if (!sp) return "";
+		for (auto const& kv : storage) if (kv.second == sp) return kv.first;
+		return "";
+	};
+	u32(uint32_t(scene.instances.meshes.size()));
+	for (auto const& name : sorted(scene.instances.meshes)) {
+		auto const& in = *scene.instances.meshes.at(name);
+		str(name), str(name_of(scene.meshes, in.mesh)), str(name_of(scene.materials, in.material)), u32(in.settings.visible ? 1 : 0);
+		mat(in.transform.lock()->local_to_world());
+	}
+	u32(uint32_t(scene.instances.shapes.size()));
+	for (auto const& name : sorted(scene.instances.shapes)) {
+		auto const& in = *scene.instances.shapes.at(name);
+		auto shape = in.shape.lock();
+		str(name), f32(shape ? std::get<Shapes::Sphere>(shape->shape).radius : 0.0f), str(name_of(scene.materials, in.material)), u32(in.settings.visible ? 1 : 0);
+		mat(in.transform.lock()->local_to_world());
+	}
+	u32(uint32_t(scene.instances.cameras.size()));
+	for (auto const& name : sorted(scene.instances.cameras)) {
+		auto const& in = *scene.instances.cameras.at(name);
+		auto cam = in.camera.lock();
+		str(name), mat(in.transform.lock()->local_to_world());
+		f32(cam->vertical_fov), f32(cam->aspect_ratio), u32(cam->film.width), u32(cam->film.height), u32(cam->film.samples), u32(cam->film.max_ray_depth);
+	}
+	u32(uint32_t(scene.instances.delta_lights.size()));
+	for (auto const& name : sorted(scene.instances.delta_lights)) {
+		auto const& in = *scene.instances.delta_lights.at(name);
+		auto l = in.light.lock();
+		str(name);
+		if (l->is<Delta_Lights::Point>()) {
+			auto const& p = std::get<Delta_Lights::Point>(l->light);
+			u32(0), f32(p.color.r), f32(p.color.g), f32(p.color.b), f32(p.intensity), f32(0), f32(0);
+		} else if (l->is<Delta_Lights::Directional>()) {
+			auto const& p = std::get<Delta_Lights::Directional>(l->light);
+			u32(1), f32(p.color.r), f32(p.color.g), f32(p.color.b), f32(p.intensity), f32(0), f32(0);
+		} else {
+			auto const& p = std::get<Delta_Lights::Spot>(l->light);
+			u32(2), f32(p.color.r), f32(p.color.g), f32(p.color.b), f32(p.intensity), f32(p.inner_angle), f32(p.outer_angle);
+		}
+		u32(in.settings.visible ? 1 : 0), mat(in.transform.lock()->local_to_world());
+	}
+	if (out && buf.size() <= cap) std::memcpy(out, buf.data(), buf.size());
+	return buf.size();
 }
 
 }  // extern "C"

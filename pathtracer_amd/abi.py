@@ -187,3 +187,68 @@ class SceneBuilder:
         d.use_bvh, d.fresnel_mode = (1 if self.use_bvh else 0), self.fresnel_mode
         self._keep.append(d)
         return d
+
+
+def desc_to_arrays(desc, cameras=None):
+    """Flattens a PtxSceneDesc (and optionally {name: PtxCamera}) into a dict of numpy arrays (np.savez-able)."""
+    out = {"n_meshes": np.uint32(desc.n_meshes), "use_bvh": np.uint32(desc.use_bvh), "fresnel_mode": np.uint32(desc.fresnel_mode)}
+    for i in range(desc.n_meshes):
+        m = desc.meshes[i]
+        out[f"mesh{i}_verts"] = np.ctypeslib.as_array(m.verts, shape=(m.n_verts, 8)).copy() if m.n_verts else np.zeros((0, 8), np.float32)
+        out[f"mesh{i}_indices"] = np.ctypeslib.as_array(m.indices, shape=(m.n_tris, 3)).copy() if m.n_tris else np.zeros((0, 3), np.uint32)
+        out[f"mesh{i}_opts"] = np.array([m.use_bvh, m.max_leaf_size], dtype=np.uint32)
+    out["instances"] = np.array([[in_.mesh, in_.material] for in_ in desc.instances[:desc.n_instances]], dtype=np.int32).reshape(-1, 2)
+    out["instance_radius"] = np.array([in_.sphere_radius for in_ in desc.instances[:desc.n_instances]], dtype=np.float32)
+    out["instance_T"] = np.array([list(in_.T) for in_ in desc.instances[:desc.n_instances]], dtype=np.float32).reshape(-1, 16)
+    tex = desc.textures[:desc.n_textures]
+    out["textures"] = np.array([[t.type, t.sampler, t.w, t.h] for t in tex], dtype=np.uint32).reshape(-1, 4)
+    out["texture_color"] = np.array([[t.color[0], t.color[1], t.color[2], t.scale] for t in tex], dtype=np.float32).reshape(-1, 4)
+    for i, t in enumerate(tex):
+        if t.type == PTX_TEX_IMAGE:
+            out[f"tex{i}_pixels"] = np.ctypeslib.as_array(t.pixels, shape=(t.h, t.w, 3)).copy()
+    mats = desc.materials[:desc.n_materials]
+    out["materials"] = np.array([[m.type, m.tex_a, m.tex_b] for m in mats], dtype=np.int32).reshape(-1, 3)
+    out["material_ior"] = np.array([m.ior for m in mats], dtype=np.float32)
+    dl = desc.delta_lights[:desc.n_delta_lights]
+    out["delta_light_type"] = np.array([l.type for l in dl], dtype=np.uint32)
+    out["delta_light_params"] = np.array([[l.color[0], l.color[1], l.color[2], l.intensity, l.inner_angle, l.outer_angle] for l in dl], dtype=np.float32).reshape(-1, 6)
+    out["delta_light_T"] = np.array([list(l.T) for l in dl], dtype=np.float32).reshape(-1, 16)
+    out["env_lights"] = np.array([[l.type, l.tex] for l in desc.env_lights[:desc.n_env_lights]], dtype=np.int32).reshape(-1, 2)
+    if cameras:
+        names = sorted(cameras)
+        out["camera_names"] = np.array(names)
+        out["camera_lens"] = np.array([[cameras[n].vertical_fov, cameras[n].aspect_ratio] for n in names], dtype=np.float32)
+        out["camera_film"] = np.array([[cameras[n].film_width, cameras[n].film_height, cameras[n].film_samples, cameras[n].film_max_ray_depth] for n in names], dtype=np.uint32)
+        out["camera_T"] = np.array([list(cameras[n].camera_to_world) for n in names], dtype=np.float32)
+    return out
+
+
+def builder_from_arrays(a):
+    """Inverse of desc_to_arrays: (SceneBuilder, {name: PtxCamera})."""
+    sb = SceneBuilder(use_bvh=bool(a["use_bvh"]), fresnel_mode=int(a["fresnel_mode"]))
+    for i in range(int(a["n_meshes"])):
+        opts = a[f"mesh{i}_opts"]
+        sb.add_mesh(a[f"mesh{i}_verts"], a[f"mesh{i}_indices"], use_bvh=bool(opts[0]), max_leaf_size=int(opts[1]))
+    for i, (t, c) in enumerate(zip(a["textures"], a["texture_color"])):
+        if int(t[0]) == PTX_TEX_IMAGE:
+            sb.add_image_texture(a[f"tex{i}_pixels"], int(t[1]))
+        else:
+            sb.add_constant_texture(tuple(float(x) for x in c[:3]), float(c[3]))
+    for m, ior in zip(a["materials"], a["material_ior"]):
+        sb.add_material(int(m[0]), int(m[1]), int(m[2]), float(ior))
+    for (mesh, mat), radius, T in zip(a["instances"], a["instance_radius"], a["instance_T"]):
+        sb.add_instance(int(mesh), int(mat), T, float(radius))
+    for t, p, T in zip(a["delta_light_type"], a["delta_light_params"], a["delta_light_T"]):
+        sb.add_delta_light(int(t), tuple(float(x) for x in p[:3]), float(p[3]), T, float(p[4]), float(p[5]))
+    for t, tex in a["env_lights"]:
+        sb.add_env_light(int(t), int(tex))
+    cams = {}
+    if "camera_names" in a:
+        for n, lens, film, T in zip(a["camera_names"], a["camera_lens"], a["camera_film"], a["camera_T"]):
+            cam = PtxCamera()
+            cam.vertical_fov, cam.aspect_ratio = float(lens[0]), float(lens[1])
+            cam.film_width, cam.film_height, cam.film_samples, cam.film_max_ray_depth = (int(x) for x in film)
+            for k in range(16):
+                cam.camera_to_world[k] = float(T[k])
+            cams[str(n)] = cam
+    return sb, cams

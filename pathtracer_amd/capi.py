@@ -70,6 +70,24 @@ def lib():
     L.ptx_accumulator_to_image.argtypes = [vp, vp, C.c_uint64, vp]
     L.ptx_tonemap.argtypes = [vp, C.c_uint64, C.c_float, vp]
     L.ptx_get_counters.argtypes = [vp, C.POINTER(abi.PtxCounters)]
+    L.ptx_js3d_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.ptx_js3d_free.argtypes = [vp]
+    L.ptx_js3d_free.restype = None
+    L.ptx_js3d_scene_desc.argtypes = [vp]
+    L.ptx_js3d_scene_desc.restype = C.POINTER(abi.PtxSceneDesc)
+    L.ptx_js3d_set_modes.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.ptx_js3d_set_modes.restype = None
+    L.ptx_js3d_num_cameras.argtypes = [vp]
+    L.ptx_js3d_num_cameras.restype = C.c_uint32
+    L.ptx_js3d_num_meshes.argtypes = [vp]
+    L.ptx_js3d_num_meshes.restype = C.c_uint32
+    for f in ("ptx_js3d_camera_name", "ptx_js3d_mesh_name", "ptx_js3d_instance_name"):
+        getattr(L, f).argtypes = [vp, C.c_uint32]
+        getattr(L, f).restype = C.c_char_p
+    L.ptx_js3d_warnings.argtypes = [vp]
+    L.ptx_js3d_warnings.restype = C.c_char_p
+    L.ptx_js3d_get_camera.argtypes = [vp, C.c_char_p, C.POINTER(abi.PtxCamera)]
+    L.ptx_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_int]
     _lib = L
     return L
 
@@ -226,6 +244,62 @@ class Scene:
         c = abi.PtxCounters()
         check(lib().ptx_get_counters(self.h, C.byref(c)))
         return c
+
+
+class Js3d:
+    """A scene file of the reference's JSON format, flattened to a PtxSceneDesc (ptx_js3d_t)."""
+
+    def __init__(self, path):
+        self.h = vp()
+        check(lib().ptx_js3d_load(os.fsencode(path), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().ptx_js3d_free(self.h)
+            self.h = vp()
+
+    __del__ = close
+
+    @property
+    def desc(self):
+        """PtxSceneDesc whose arrays live as long as this object."""
+        return lib().ptx_js3d_scene_desc(self.h).contents
+
+    def set_modes(self, use_bvh=True, fresnel_mode=abi.PTX_FRESNEL_GCC_INT_ABS):
+        lib().ptx_js3d_set_modes(self.h, 1 if use_bvh else 0, fresnel_mode)
+
+    def camera_names(self):
+        return [lib().ptx_js3d_camera_name(self.h, i).decode() for i in range(lib().ptx_js3d_num_cameras(self.h))]
+
+    def camera(self, name):
+        cam = abi.PtxCamera()
+        check(lib().ptx_js3d_get_camera(self.h, name.encode(), C.byref(cam)))
+        return cam
+
+    def mesh_names(self):
+        return [lib().ptx_js3d_mesh_name(self.h, i).decode() for i in range(lib().ptx_js3d_num_meshes(self.h))]
+
+    def instance_names(self):
+        return [lib().ptx_js3d_instance_name(self.h, i).decode() for i in range(self.desc.n_instances)]
+
+    def warnings(self):
+        return lib().ptx_js3d_warnings(self.h).decode()
+
+    def mesh_arrays(self, i):
+        """(verts n x 8 float32, indices m x 3 uint32) of mesh i, copied out."""
+        m = self.desc.meshes[i]
+        verts = np.ctypeslib.as_array(m.verts, shape=(m.n_verts, 8)).copy() if m.n_verts else np.zeros((0, 8), np.float32)
+        idx = np.ctypeslib.as_array(m.indices, shape=(m.n_tris, 3)).copy() if m.n_tris else np.zeros((0, 3), np.uint32)
+        return verts, idx
+
+    def scene(self, device=0):
+        return Scene(self.desc, device=device, keep=self)
+
+
+def write_png(path, rgba, width, height, flip_rows=True):
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    assert rgba.size == width * height * 4
+    check(lib().ptx_write_png(os.fsencode(path), rgba.ctypes.data, width, height, 1 if flip_rows else 0))
 
 
 def selftest_division(pairs, seed=1, device=0):

@@ -16,6 +16,14 @@ Fixtures (all little-endian numpy .npz):
   builder.npz          node arrays of the reference builder (digest + head) for the meshes above
   probes.npz           BBox::hit, Triangle::hit, Sphere::hit, Mat4::inverse, rotate_to, RNG::unit,
                        Materials::*::scatter on seeded inputs
+  scene_<name>.npz     media/js3d/<name>.js3d flattened to the scene descriptor arrays (meshes as the
+                       reference's Indexed_Mesh::from_halfedge_mesh(SplitEdges) produces them, instance
+                       transforms, materials, cameras) -- checked here against the reference's own
+                       loader byte for byte before it is written
+  image_<name>_<mode>.npz   64x64 renders of those scenes by the CPU checker with the reference's
+                       mt19937-per-tile stream (the reference's Pathtracer itself cannot be built in this
+                       image: pathtracer.cpp needs SDL.h): 4096 spp image, and the RMSE of an independent
+                       1024 spp render against it (the noise level a 1024 spp render is held to)
 """
 import hashlib
 import os
@@ -29,7 +37,118 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 from pathtracer_amd import abi, capi, synth  # noqa: E402
 import scenes  # noqa: E402
-from _oracle import Ref  # noqa: E402
+from _oracle import Oracle, Ref  # noqa: E402
+import ctypes as C  # noqa: E402
+import struct  # noqa: E402
+
+MEDIA = "/root/reference/media/js3d"
+
+
+def ref_flatten(ref, path):
+    """The reference loader's view of a scene file: {mesh name: (verts, indices)}, {instance name: (mesh, material, visible, T)}."""
+    f = ref.L.ref_js3d_flatten
+    f.restype, f.argtypes = C.c_uint64, [C.c_char_p, C.c_void_p, C.c_uint64]
+    n = f(path.encode(), None, 0)
+    buf = np.zeros(n, np.uint8)
+    f(path.encode(), buf.ctypes.data, n)
+    b, pos = buf.tobytes(), 0
+
+    def u32():
+        nonlocal pos
+        v = struct.unpack_from("<I", b, pos)[0]
+        pos += 4
+        return v
+
+    def string():
+        nonlocal pos
+        k = u32()
+        v = b[pos:pos + k].decode()
+        pos += k
+        return v
+
+    def arr(dtype, k):
+        nonlocal pos
+        v = np.frombuffer(b, dtype, k, pos).copy()
+        pos += 4 * k
+        return v
+
+    meshes, insts, shapes, cams, lights = {}, {}, {}, {}, {}
+    for _ in range(u32()):
+        name, nv, ni = string(), u32(), u32()
+        meshes[name] = (arr(np.float32, nv * 8).reshape(-1, 8), arr(np.uint32, ni).reshape(-1, 3))
+    for _ in range(u32()):
+        name = string()
+        insts[name] = (string(), string(), u32(), arr(np.float32, 16))
+    for _ in range(u32()):
+        name = string()
+        shapes[name] = (float(arr(np.float32, 1)[0]), string(), u32(), arr(np.float32, 16))
+    for _ in range(u32()):
+        name = string()
+        cams[name] = (arr(np.float32, 16), arr(np.float32, 2), arr(np.uint32, 4))
+    for _ in range(u32()):
+        name = string()
+        lights[name] = (u32(), arr(np.float32, 6), u32(), arr(np.float32, 16))
+    return dict(meshes=meshes, mesh_instances=insts, shape_instances=shapes, cameras=cams, delta_lights=lights)
+
+
+def check_reader_against_reference(ref, path):
+    """Asserts the product's scene reader and the reference's loader agree exactly; returns the reader's object."""
+    j = capi.Js3d(path)
+    r = ref_flatten(ref, path)
+    d = j.desc
+    names = j.mesh_names()
+    assert names == sorted(r["meshes"])
+    for i, n in enumerate(names):
+        v, idx = j.mesh_arrays(i)
+        assert v.tobytes() == r["meshes"][n][0].tobytes() and idx.tobytes() == r["meshes"][n][1].tobytes(), (path, n)
+    inst_names = j.instance_names()
+    expect = [n for n in sorted(r["mesh_instances"]) if r["mesh_instances"][n][2]] + [n for n in sorted(r["shape_instances"]) if r["shape_instances"][n][2]]
+    assert inst_names == expect, (inst_names, expect)
+    for k, n in enumerate(inst_names):
+        T = (r["mesh_instances"].get(n) or r["shape_instances"].get(n))[3]
+        assert np.array(d.instances[k].T[:], np.float32).tobytes() == T.tobytes(), (path, n)
+    for n in j.camera_names():
+        c = j.camera(n)
+        T, lens, film = r["cameras"][n]
+        assert np.array(c.camera_to_world[:], np.float32).tobytes() == T.tobytes()
+        assert (np.float32(c.vertical_fov), np.float32(c.aspect_ratio)) == tuple(lens)
+        assert (c.film_width, c.film_height, c.film_samples, c.film_max_ray_depth) == tuple(int(x) for x in film)
+    return j
+
+
+def camera_for(cam, w, h, spp, depth):
+    c = abi.PtxCamera()
+    C.memmove(C.byref(c), C.byref(cam), C.sizeof(c))
+    c.film_width, c.film_height, c.film_samples, c.film_max_ray_depth = w, h, spp, depth
+    c.aspect_ratio = w / float(h)      # main.cpp:139-143
+    return c
+
+
+def scene_and_image_fixtures(ref):
+    oracle = Oracle()
+    for name, depth in (("cbox", 4), ("refract_cow_cbox", 8)):
+        j = check_reader_against_reference(ref, f"{MEDIA}/{name}.js3d")
+        cams = {n: j.camera(n) for n in j.camera_names()}
+        np.savez_compressed(os.path.join(HERE, f"scene_{name}.npz"), **abi.desc_to_arrays(j.desc, cams))
+        for mode, fm in (("gcc_int_abs", abi.PTX_FRESNEL_GCC_INT_ABS), ("float_abs", abi.PTX_FRESNEL_FLOAT_ABS)):
+            j.set_modes(True, fm)
+            sc = oracle.scene(j.desc)
+            w = h = 64
+            big = camera_for(cams["Camera_instance"], w, h, 4096, depth)
+            small = camera_for(cams["Camera_instance"], w, h, 1024, depth)
+            img = capi.accumulator_to_image(*sc.render_tiles(big, capi.make_tiles(w, h, 4096, 4660), 0, 0))
+            img2 = capi.accumulator_to_image(*sc.render_tiles(small, capi.make_tiles(w, h, 1024, 977), 0, 0))
+            sc.close()
+            np.savez_compressed(os.path.join(HERE, f"image_{name}_{mode}.npz"), image=img.reshape(h, w, 3), spp=np.uint32(4096), depth=np.uint32(depth),
+                                rmse_1024spp=np.float32(np.sqrt(((img - img2) ** 2).mean())), mean=img.mean(axis=0))
+            print(name, mode, "mean", img.mean(axis=0), "rmse@1024", np.sqrt(((img - img2) ** 2).mean()))
+    # every bundled scene that the reader handles agrees with the reference's loader
+    for f in sorted(os.listdir(MEDIA)):
+        try:
+            check_reader_against_reference(ref, f"{MEDIA}/{f}").close()
+            print("reader == reference loader:", f)
+        except capi.PtxError as e:
+            print("reader declines", f, "--", e)
 
 N_RAYS = 4096
 
@@ -193,6 +312,7 @@ def main():
     p.update(env_image=img, env_dirs=edirs.astype(np.float32), env_bilinear=ref.env_sphere_evaluate(img, abi.PTX_SAMPLER_BILINEAR, edirs),
              env_nearest=ref.env_sphere_evaluate(img, abi.PTX_SAMPLER_NEAREST, edirs))
     np.savez_compressed(os.path.join(HERE, "probes.npz"), **p)
+    scene_and_image_fixtures(ref)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

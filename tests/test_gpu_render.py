@@ -162,3 +162,32 @@ def test_render_device_accumulator_and_errors():
     with pytest.raises(capi.PtxError):
         gsc.render_tiles(cam, bad, SEED)
     gsc.close()
+
+
+GOLDEN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["cbox", "refract_cow_cbox"])
+@pytest.mark.parametrize("mode,fresnel", [("gcc_int_abs", abi.PTX_FRESNEL_GCC_INT_ABS), ("float_abs", abi.PTX_FRESNEL_FLOAT_ABS)])
+def test_image_gate_on_reference_scenes(name, mode, fresnel):
+    """media/js3d/cbox.js3d and refract_cow_cbox.js3d (committed as descriptor fixtures) at 64x64, 1024 spp:
+    RMSE against the checker's 4096 spp image (mt19937-per-tile stream, linear radiance) within 1.5x the RMSE
+    an independent 1024 spp checker render has against that image.  Both Fresnel behaviours."""
+    import ctypes as C
+    g = np.load(f"{GOLDEN}/scene_{name}.npz", allow_pickle=False)
+    img = np.load(f"{GOLDEN}/image_{name}_{mode}.npz", allow_pickle=False)
+    sb, cams = abi.builder_from_arrays(g)
+    sb.fresnel_mode = fresnel
+    cam = cams["Camera_instance"]
+    w = h = 64
+    cam.film_width, cam.film_height, cam.film_samples, cam.film_max_ray_depth = w, h, 1024, int(img["depth"])
+    cam.aspect_ratio = 1.0
+    sc = capi.Scene(sb.desc(), keep=sb)
+    acc, smp = sc.render_tiles(cam, capi.make_tiles(w, h, 1024, 31), SEED)
+    sc.close()
+    assert (smp == 1024).all()
+    got = capi.accumulator_to_image(acc, smp)
+    ref_img = img["image"].reshape(-1, 3)
+    rmse = float(np.sqrt(((got - ref_img) ** 2).mean()))
+    assert rmse <= 1.5 * float(img["rmse_1024spp"]), (rmse, float(img["rmse_1024spp"]))
+    np.testing.assert_allclose(got.mean(axis=0), img["mean"], rtol=0.03)

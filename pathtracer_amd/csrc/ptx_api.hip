@@ -533,13 +533,17 @@ int ptx_scene_create(int device, const PtxSceneDesc* d, ptx_scene_t* out) {
 		texs.push_back(r);
 	}
 	std::vector<MatRec> mats;
+	std::vector<bool> material_ok;
 	for (uint32_t i = 0; i < d->n_materials; i++) {
 		const auto& m = d->materials[i];
 		if (m.type > PTX_MAT_EMISSIVE) return bail(fail(PTX_ERR_INVALID, "unknown material type"));
 		const bool needs_a = m.type != PTX_MAT_REFRACT, needs_b = m.type == PTX_MAT_REFRACT || m.type == PTX_MAT_GLASS;
-		if ((needs_a && (m.tex_a < 0 || m.tex_a >= default_tex)) || (needs_b && (m.tex_b < 0 || m.tex_b >= default_tex)))
-			return bail(fail(PTX_ERR_INVALID, "material references a texture that does not exist"));
-		mats.push_back(MatRec{m.type, m.tex_a, m.tex_b, m.ior});
+		// A material whose texture reference dangles may sit unused in a scene file (the reference
+		// keeps an expired weak_ptr there and only fails if the material is ever evaluated): such a
+		// material is accepted, and rejected only when an instance uses it.
+		const bool bad_a = needs_a && (m.tex_a < 0 || m.tex_a >= default_tex), bad_b = needs_b && (m.tex_b < 0 || m.tex_b >= default_tex);
+		material_ok.push_back(!(bad_a || bad_b));
+		mats.push_back(MatRec{m.type, bad_a ? default_tex : m.tex_a, bad_b ? default_tex : m.tex_b, m.ior});
 	}
 	const int default_mat = int(mats.size());
 	mats.push_back(MatRec{PTX_MAT_LAMBERTIAN, default_tex, -1, 1.5f});
@@ -579,6 +583,7 @@ int ptx_scene_create(int device, const PtxSceneDesc* d, ptx_scene_t* out) {
 		r.has_transform = mat4_is_identity(T) ? 0 : 1;
 		r.mesh = in.mesh < 0 ? -1 : in.mesh;
 		r.radius = in.sphere_radius;
+		if (in.material >= 0 && !material_ok[size_t(in.material)]) return bail(fail(PTX_ERR_INVALID, "an instance uses a material that references a texture that does not exist"));
 		r.material = in.material < 0 ? default_mat : in.material;
 		float box[6];
 		if (r.mesh >= 0) {

@@ -277,6 +277,12 @@ typedef struct PtxCounters {
 	uint64_t paths;          /* camera samples traced by ptx_render_tiles */
 } PtxCounters;
 int ptx_get_counters(ptx_scene_t scene, PtxCounters* out);
+/* Device time of the single-mesh traversal kernel (the dominant kernel of ptx_trace_closest /
+ * ptx_trace_any on a ptx_scene_create_mesh scene), from HIP events recorded on the scene's stream
+ * around each launch: the last min(launches, 64, cap) durations in milliseconds, oldest first.
+ * Waits for the stream.  Stands where the reference's build_timer / render_timer stand
+ * (pathtracer.h:76, completion_time(), pathtracer.cpp:483-485). */
+int ptx_get_kernel_times(ptx_scene_t scene, float* ms, uint32_t cap, uint32_t* n_out);
 
 /* ------------------------------------------------------------------ scene files and image output */
 /* The reference's JSON scene format ("js3d-v1"): load(filepath, &scene, &animator)

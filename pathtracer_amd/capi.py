@@ -70,6 +70,7 @@ def lib():
     L.ptx_accumulator_to_image.argtypes = [vp, vp, C.c_uint64, vp]
     L.ptx_tonemap.argtypes = [vp, C.c_uint64, C.c_float, vp]
     L.ptx_get_counters.argtypes = [vp, C.POINTER(abi.PtxCounters)]
+    L.ptx_get_kernel_times.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.ptx_js3d_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.ptx_js3d_free.argtypes = [vp]
     L.ptx_js3d_free.restype = None
@@ -239,6 +240,13 @@ class Scene:
             flags |= abi.PTX_MEM_DEVICE
         check(lib().ptx_render_tiles(self.h, C.byref(cam), tiles.ctypes.data, len(tiles), seed, a, _addr(samples)[0], flags))
         return accum, samples
+
+    def kernel_times_ms(self, last=64):
+        """Device durations (ms) of the last traversal-kernel launches, oldest first (waits for the stream)."""
+        out = np.zeros(last, dtype=np.float32)
+        n = C.c_uint32()
+        check(lib().ptx_get_kernel_times(self.h, out.ctypes.data, last, C.byref(n)))
+        return out[:n.value]
 
     def counters(self):
         c = abi.PtxCounters()

@@ -348,6 +348,10 @@ static void free_scene(PtxScene* s) {
 	for (void* p : s->allocations) (void)hipFree(p);
 	for (void* p : s->scratch)
 		if (p) (void)hipFree(p);
+	for (uint32_t i = 0; i < PtxScene::TIMING_RING; i++) {
+		if (s->t_start[i]) (void)hipEventDestroy(s->t_start[i]);
+		if (s->t_stop[i]) (void)hipEventDestroy(s->t_stop[i]);
+	}
 	delete s;
 }
 
@@ -412,8 +416,16 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const PtxRay* 
 	static const int refill = getenv("PTX_REFILL_MIN_IDLE") ? atoi(getenv("PTX_REFILL_MIN_IDLE")) : REFILL_MIN_IDLE;
 	static const int tri_min = getenv("PTX_TRI_MIN_LANES") ? atoi(getenv("PTX_TRI_MIN_LANES")) : TRI_MIN_LANES;
 	const dim3 block(256), grid(uint32_t(std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu)))));
+	const uint32_t slot = uint32_t(s->timed_launches % PtxScene::TIMING_RING);
+	if (!s->t_start[slot]) {
+		PTX_HIP(hipEventCreate(&s->t_start[slot]));
+		PTX_HIP(hipEventCreate(&s->t_stop[slot]));
+	}
+	PTX_HIP(hipEventRecord(s->t_start[slot], s->stream));
 	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min);
 	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min);
+	PTX_HIP(hipEventRecord(s->t_stop[slot], s->stream));
+	s->timed_launches++;
 	const dim3 dgrid(uint32_t(std::min<uint64_t>(want, 1024)));
 	if (culled) hipLaunchKernelGGL((k_mesh_deferred<MODE_CULLED, ANY>), dgrid, block, 0, s->stream, s->rec, d_rays, slow_list, slow_count, d_hits, d_bary, d_inst, d_occ);
 	else hipLaunchKernelGGL((k_mesh_deferred<MODE_REFERENCE, ANY>), dgrid, block, 0, s->stream, s->rec, d_rays, slow_list, slow_count, d_hits, d_bary, d_inst, d_occ);
@@ -659,6 +671,20 @@ int ptx_scene_mesh_get_order(ptx_scene_t s, uint32_t mesh, uint32_t* out) {
 int ptx_scene_get_instance_order(ptx_scene_t s, uint32_t* out) {
 	if (!s || !out) return fail(PTX_ERR_INVALID, "ptx_scene_get_instance_order: bad argument");
 	std::copy(s->top_bvh.order.begin(), s->top_bvh.order.end(), out);
+	return PTX_OK;
+}
+
+int ptx_get_kernel_times(ptx_scene_t s, float* ms, uint32_t cap, uint32_t* n_out) {
+	if (!s || !n_out || (cap && !ms)) return fail(PTX_ERR_INVALID, "ptx_get_kernel_times: null argument");
+	PTX_HIP(hipSetDevice(s->device));
+	PTX_HIP(hipStreamSynchronize(s->stream));
+	const uint64_t have = std::min<uint64_t>(s->timed_launches, PtxScene::TIMING_RING);
+	const uint32_t n = uint32_t(std::min<uint64_t>(have, cap));
+	for (uint32_t k = 0; k < n; k++) {   // oldest of the last n first
+		const uint32_t slot = uint32_t((s->timed_launches - n + k) % PtxScene::TIMING_RING);
+		PTX_HIP(hipEventElapsedTime(&ms[k], s->t_start[slot], s->t_stop[slot]));
+	}
+	*n_out = n;
 	return PTX_OK;
 }
 

@@ -76,4 +76,9 @@ struct PtxScene {
 	// Scratch grown on demand (host-pointer calls, render state).
 	void* scratch[8] = {};
 	size_t scratch_bytes[8] = {};
+	// Device-side timing of the dominant traversal kernel: HIP events recorded on the scene's
+	// stream right before and after each launch, kept in a ring (ptx_get_kernel_times).
+	static constexpr uint32_t TIMING_RING = 64;
+	hipEvent_t t_start[TIMING_RING] = {}, t_stop[TIMING_RING] = {};
+	uint64_t timed_launches = 0;
 };

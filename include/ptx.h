@@ -230,8 +230,9 @@ int ptx_trace_closest(ptx_scene_t scene, const PtxRay* rays, uint64_t n, PtxHit*
 int ptx_trace_any(ptx_scene_t scene, const PtxRay* rays, uint64_t n, uint8_t* occluded, uint32_t flags);
 
 /* Diagnostics (no counterpart in the reference).  ptx_trace_closest_stats: the closest-hit
- * traversal instrumented; stats3[3*i + {0,1,2}] = interior nodes fetched (two box tests each),
- * leaves entered, triangles tested for ray i.  ptx_selftest_division: runs `pairs` operand
+ * traversal instrumented; stats3[3*i + {0,1,2}] = interior nodes fetched (two box tests each; low
+ * 24 bits, the high 8 bits hold the deepest traversal stack), leaves entered, triangles tested
+ * for ray i.  ptx_selftest_division: runs `pairs` operand
  * pairs through the traversal's short division form and the IEEE quotient on the device and
  * reports how many differ in any bit. */
 int ptx_trace_closest_stats(ptx_scene_t scene, const PtxRay* rays, uint64_t n, uint32_t* stats3, uint32_t flags);

@@ -211,11 +211,13 @@ class Scene:
         check(lib().ptx_trace_closest(self.h, rays.data_ptr(), n, hits.data_ptr(), _addr(bary)[0], _addr(inst)[0], flags | abi.PTX_MEM_DEVICE))
 
     def trace_closest_stats(self, rays, flags=0):
-        """Per ray: interior nodes fetched, leaves entered, triangles tested."""
+        """Per ray: interior nodes fetched, leaves entered, triangles tested, deepest traversal stack."""
         rays = np.ascontiguousarray(rays)
         assert rays.dtype == abi.RAY_DTYPE
-        out = np.zeros((len(rays), 3), dtype=np.uint32)
-        check(lib().ptx_trace_closest_stats(self.h, rays.ctypes.data, len(rays), out.ctypes.data, flags))
+        raw = np.zeros((len(rays), 3), dtype=np.uint32)
+        check(lib().ptx_trace_closest_stats(self.h, rays.ctypes.data, len(rays), raw.ctypes.data, flags))
+        out = np.zeros((len(rays), 4), dtype=np.uint32)
+        out[:, 0], out[:, 1], out[:, 2], out[:, 3] = raw[:, 0] & 0xFFFFFF, raw[:, 1], raw[:, 2], raw[:, 0] >> 24
         return out
 
     def trace_any(self, rays, flags=0):

@@ -97,3 +97,35 @@ def test_host_builder_statistics_and_guards():
     b.close()
     with pytest.raises(capi.PtxError):
         capi.Bvh(verts=verts, indices=np.array([[0, 1, 999999]], dtype=np.uint32))    # index out of range
+
+
+def _build_facade_check(tmp_path):
+    exe = str(tmp_path / "facade_check")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "facade_check.cpp"), "-o", exe,
+                           "-L" + libdir, "-lptx_amd", "-pthread", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_facade_host_side(tmp_path):
+    """PT::BVH<Triangle> / PT::Ray of the C++ facade compile against the C ABI and behave like the reference's classes."""
+    out = subprocess.check_output([_build_facade_check(tmp_path)], text=True)
+    assert "host checks passed" in out
+
+
+@pytest.mark.gpu
+def test_cpp_facade_on_gpu(tmp_path):
+    out = subprocess.check_output([_build_facade_check(tmp_path), "gpu"], text=True)
+    assert "gpu checks passed" in out
+
+
+def test_cli_reports_errors_like_the_reference(tmp_path):
+    """Exit code 1 and the reference's messages for a missing scene / unknown option (main.cpp:96-134)."""
+    cli = os.path.join(ROOT, "pathtracer_amd", "bin", "ptx_render")
+    assert os.path.exists(cli), "build it with make -C pathtracer_amd/csrc"
+    r = subprocess.run([cli, "--trace"], capture_output=True, text=True)
+    assert r.returncode == 1 and "must specify a scene file" in r.stderr
+    r = subprocess.run([cli, "--trace", "-s", str(tmp_path / "none.js3d"), "-c", "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Failed to load scene" in r.stderr
+    r = subprocess.run([cli, "-s", "x"], capture_output=True, text=True)
+    assert r.returncode == 1

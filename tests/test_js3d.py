@@ -220,3 +220,32 @@ def test_fixture_round_trip():
     a = abi.desc_to_arrays(sb.desc(), cams)
     for k in g.files:
         assert np.array_equal(a[k], g[k]), k
+
+
+@pytest.mark.gpu
+def test_cli_renders_a_scene_file(scene_file, tmp_path):
+    """ptx_render with the reference's flags (main.cpp:55-71): scene file in, tone-mapped PNG out."""
+    import subprocess
+    import zlib
+    path = scene_file[0]
+    cli = os.path.join(os.path.dirname(G), "..", "pathtracer_amd", "bin", "ptx_render")
+    out = tmp_path / "frame.png"
+    r = subprocess.run([cli, "--trace", "-s", path, "-c", "Cam_instance", "-o", str(out), "--film-width", "64", "--film-height", "48",
+                        "--film-samples", "8", "--film-max-ray-depth", "3", "--seed", "4660", "--exposure", "1.5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Set film size to [64x48]" in r.stdout and "Wrote result to" in r.stdout
+    data = out.read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    assert int.from_bytes(data[16:20], "big") == 64 and int.from_bytes(data[20:24], "big") == 48
+    n = int.from_bytes(data[33:37], "big")
+    assert data[37:41] == b"IDAT"
+    raw = np.frombuffer(zlib.decompress(data[41:41 + n]), np.uint8).reshape(48, 1 + 64 * 4)[:, 1:].reshape(48, 64, 4)
+    assert (raw[..., 3] == 255).all()
+    assert raw[..., :3].max() > 0            # the hemisphere light is visible above the horizon
+    # same flags, --no_bvh: List<Instance> / List<Triangle> give the same picture (same random stream)
+    out2 = tmp_path / "frame_list.png"
+    r = subprocess.run([cli, "--trace", "-s", path, "-c", "Cam_instance", "-o", str(out2), "--film-width", "64", "--film-height", "48",
+                        "--film-samples", "8", "--film-max-ray-depth", "3", "--seed", "4660", "--exposure", "1.5", "--no_bvh"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    raw2 = np.frombuffer(zlib.decompress(out2.read_bytes()[41:41 + n]), np.uint8).reshape(48, 1 + 64 * 4)[:, 1:].reshape(48, 64, 4)
+    assert (np.abs(raw.astype(int) - raw2.astype(int)) > 1).mean() < 0.01

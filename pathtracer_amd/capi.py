@@ -11,7 +11,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libptx_amd.so")
+LIB_PATH = os.environ.get("PTX_AMD_LIB") or os.path.join(_HERE, "lib", "libptx_amd.so")   # the override serves tuning experiments
 
 vp = C.c_void_p
 _lib = None

@@ -17,8 +17,13 @@
 namespace ptx {
 
 constexpr int REFILL_MIN_IDLE = 8;    // refill when at least this many of the 64 slots are dry
-constexpr int TRI_MIN_LANES = 1;      // run the triangle step when at least this many lanes stand in a leaf
-constexpr int PERSISTENT_LDS_SLOTS = 12;   // stack entries per lane kept in LDS (8 B each)
+constexpr int TRI_MIN_LANES = 1;      // reference order: run the triangle step when at least this many lanes stand in a leaf
+constexpr int PARK_MIN_LANES = 32;    // culled order: run the triangle phase when this many lanes have a leaf parked ...
+constexpr int STUCK_MAX_LANES = 16;   // ... or this many lanes cannot go on walking until their parked leaf is tested
+#ifndef PTX_LDS_SLOTS
+#define PTX_LDS_SLOTS 12
+#endif
+constexpr int PERSISTENT_LDS_SLOTS = PTX_LDS_SLOTS;   // stack entries per lane kept in LDS (8 B each)
 constexpr unsigned long long WAVE_CHUNK = 256;    // consecutive ray slots a wave claims at a time
 
 template<int MODE, bool ANY>
@@ -26,7 +31,7 @@ __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxR
                                                          float* __restrict__ bary, uint32_t* __restrict__ inst, uint8_t* __restrict__ occluded,
                                                          unsigned long long* __restrict__ next_ray, const int refill_min_idle,
                                                          const uint32_t* __restrict__ order, uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count,
-                                                         const int tri_min_lanes) {
+                                                         const int tri_min_lanes, const int stuck_max_lanes) {
 	const MeshRec mesh = sc.meshes[0];
 	const TriGeom* __restrict__ tris = sc.tris + mesh.tri_base;
 	const Node2* __restrict__ nodes = sc.nodes + mesh.node_base;
@@ -37,7 +42,11 @@ __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxR
 	__shared__ float lds_tnear[PERSISTENT_LDS_SLOTS * 256];
 	Stack spill;
 	LdsStack<PERSISTENT_LDS_SLOTS, 256> st{lds_ref + threadIdx.x, lds_tnear + threadIdx.x, &spill};
+	// Parking leaves reorders triangle tests: fine for the culled mode (its tie rule is order free),
+	// not for the reference order.
+	constexpr bool POSTPONE = MODE == MODE_CULLED;
 	int sp = 0;
+	uint32_t pend = 0u;               // a leaf reference parked for the next triangle phase (0: none)
 	uint32_t ref = REF_DONE;          // REF_DONE + have_ray == false: the slot is dry
 	uint32_t tri_k = 0;               // next triangle of the leaf `ref` stands in
 	bool have_ray = false;
@@ -62,6 +71,9 @@ __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxR
 		have_ray = false;
 	};
 
+#ifdef PTX_PROFILE_LANES
+	unsigned long long prof_iters = 0, prof_node_lanes = 0, prof_tri_lanes = 0, prof_node_iters = 0, prof_tri_iters = 0, prof_busy = 0;
+#endif
 	for (;;) {
 		// ---- replenish dry slots
 		const unsigned long long dry = __ballot(!have_ray);
@@ -110,11 +122,59 @@ __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxR
 				}
 			}
 		}
+		if (POSTPONE) {
+			// ---- box-test step for every lane standing on an interior node.  A lane that reaches a
+			// leaf does not stop for it: it parks the leaf in `pend` and goes on with its next pending
+			// subtree, so the triangle code below runs rarely and with many lanes instead of every
+			// iteration with a few.  A parked leaf is tested later than it would have been, so the
+			// cull limit the lane uses meanwhile is looser (never tighter) than it could be: the
+			// outcome is unchanged because the culled mode's result does not depend on test order.
+			const unsigned long long on_node = __ballot(!(ref & REF_LEAF));
+#ifdef PTX_PROFILE_LANES
+			prof_iters++, prof_node_lanes += __popcll(on_node), prof_node_iters += on_node != 0ull, prof_busy += __popcll(__ballot(have_ray));
+#endif
+			if (on_node != 0ull) {
+				if (!(ref & REF_LEAF)) node_step<MODE, ANY, true, false>(nodes, r, inv, st, 0, sp, ref, cur.hit, cur.distance, nullptr);
+			}
+			if ((ref & REF_LEAF) && ref != REF_DONE && pend == 0u) {
+				if (ref & 15u) pend = ref;   // an empty leaf has nothing to test
+				pop_ref<MODE, ANY>(r, st, 0, sp, ref, cur.hit, cur.distance);
+			}
+			// ---- triangle phase: when enough leaves are parked, or too many lanes cannot go on
+			// (a second leaf reached, or the walk finished, while one is still parked)
+			const unsigned long long parked = __ballot(pend != 0u);
+			const unsigned long long stuck = __ballot(pend != 0u && (ref & REF_LEAF));
+			const unsigned long long walking = __ballot(!(ref & REF_LEAF));
+			if (parked != 0ull && (__popcll(parked) >= tri_min_lanes || __popcll(stuck) >= stuck_max_lanes || walking == 0ull)) {
+#ifdef PTX_PROFILE_LANES
+				prof_tri_lanes += __popcll(parked), prof_tri_iters++;
+#endif
+				if (pend != 0u) {
+					const bool stop = mesh_leaf<MODE, ANY, false>(tris, (pend & REF_INDEX_MASK) >> 4, pend & 15u, r, cur, nullptr);
+					pend = 0u;
+					if (stop) {
+						ref = REF_DONE, sp = 0;
+					} else if ((ref & REF_LEAF) && ref != REF_DONE) {   // the leaf this lane was held up by
+						if (ref & 15u) pend = ref;
+						pop_ref<MODE, ANY>(r, st, 0, sp, ref, cur.hit, cur.distance);
+					}
+				}
+			}
+			if (ref == REF_DONE && pend == 0u && have_ray) store_result();
+			continue;
+		}
 		// ---- one step for every busy slot: a box-test step for the lanes standing on an interior
 		// node, then one triangle for the lanes standing in a leaf.  The load/return path of the
 		// CU's vector memory pipeline is paid per wave instruction, however few lanes are active,
 		// so the step is shaped to advance as many lanes as possible per memory instruction.
 		const unsigned long long on_node = __ballot(!(ref & REF_LEAF));
+#ifdef PTX_PROFILE_LANES
+		prof_iters++, prof_node_lanes += __popcll(on_node), prof_node_iters += on_node != 0ull, prof_busy += __popcll(__ballot(have_ray));
+		{
+			const unsigned long long lf = __ballot(ref != REF_DONE && (ref & REF_LEAF));
+			prof_tri_lanes += __popcll(lf), prof_tri_iters += lf != 0ull;
+		}
+#endif
 		if (on_node != 0ull) {
 			if (!(ref & REF_LEAF)) {
 				node_step<MODE, ANY, true, false>(nodes, r, inv, st, 0, sp, ref, cur.hit, cur.distance, nullptr);
@@ -141,6 +201,12 @@ __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxR
 		}
 		if (ref == REF_DONE && have_ray) store_result();
 	}
+#ifdef PTX_PROFILE_LANES
+	if (lane == 0) {
+		atomicAdd(next_ray + 16, prof_iters), atomicAdd(next_ray + 17, prof_node_lanes), atomicAdd(next_ray + 18, prof_tri_lanes);
+		atomicAdd(next_ray + 19, prof_node_iters), atomicAdd(next_ray + 20, prof_tri_iters), atomicAdd(next_ray + 21, prof_busy);
+	}
+#endif
 }
 
 // The rays k_mesh_persistent set aside: one ray per lane, plain `/` divisions.

@@ -414,7 +414,9 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const PtxRay* 
 	// Tuning knobs for experiments (not part of the ABI): blocks per CU and the refill threshold.
 	static const int blocks_per_cu = getenv("PTX_BLOCKS_PER_CU") ? atoi(getenv("PTX_BLOCKS_PER_CU")) : 8;
 	static const int refill = getenv("PTX_REFILL_MIN_IDLE") ? atoi(getenv("PTX_REFILL_MIN_IDLE")) : REFILL_MIN_IDLE;
-	static const int tri_min = getenv("PTX_TRI_MIN_LANES") ? atoi(getenv("PTX_TRI_MIN_LANES")) : TRI_MIN_LANES;
+	static const char* tri_env = getenv("PTX_TRI_MIN_LANES");
+	const int tri_min = tri_env ? atoi(tri_env) : (culled ? PARK_MIN_LANES : TRI_MIN_LANES);
+	static const int stuck_max = getenv("PTX_STUCK_MAX_LANES") ? atoi(getenv("PTX_STUCK_MAX_LANES")) : STUCK_MAX_LANES;
 	const dim3 block(256), grid(uint32_t(std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu)))));
 	const uint32_t slot = uint32_t(s->timed_launches % PtxScene::TIMING_RING);
 	if (!s->t_start[slot]) {
@@ -422,10 +424,19 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const PtxRay* 
 		PTX_HIP(hipEventCreate(&s->t_stop[slot]));
 	}
 	PTX_HIP(hipEventRecord(s->t_start[slot], s->stream));
-	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min);
-	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min);
+	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max);
+	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max);
 	PTX_HIP(hipEventRecord(s->t_stop[slot], s->stream));
 	s->timed_launches++;
+#ifdef PTX_PROFILE_LANES
+	{
+		unsigned long long h[32];
+		PTX_HIP(hipStreamSynchronize(s->stream));
+		PTX_HIP(hipMemcpy(h, s->next_ray, sizeof(h), hipMemcpyDeviceToHost));
+		std::fprintf(stderr, "[lanes] wave-iterations %llu, node phase ran in %llu with %.1f lanes, triangle phase ran in %llu with %.1f lanes, lanes holding a ray %.1f\n", h[16], h[19],
+		             double(h[17]) / double(h[19] ? h[19] : 1), h[20], double(h[18]) / double(h[20] ? h[20] : 1), double(h[21]) / double(h[16] ? h[16] : 1));
+	}
+#endif
 	const dim3 dgrid(uint32_t(std::min<uint64_t>(want, 1024)));
 	if (culled) hipLaunchKernelGGL((k_mesh_deferred<MODE_CULLED, ANY>), dgrid, block, 0, s->stream, s->rec, d_rays, slow_list, slow_count, d_hits, d_bary, d_inst, d_occ);
 	else hipLaunchKernelGGL((k_mesh_deferred<MODE_REFERENCE, ANY>), dgrid, block, 0, s->stream, s->rec, d_rays, slow_list, slow_count, d_hits, d_bary, d_inst, d_occ);

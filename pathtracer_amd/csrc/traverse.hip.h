@@ -123,6 +123,31 @@ __device__ __forceinline__ bool slab_test(float minx, float miny, float minz, fl
 	return true;
 }
 
+// The same decision from approximate entry/exit distances, for rays and trees in the exact-division
+// range (no zero direction component, no NaN or infinity anywhere).
+//
+// BBox::hit accepts exactly when LO <= HI and HI >= 0, with LO the largest of the three per-axis
+// entry quotients and HI the smallest of the three exit quotients: the per-axis swap (bbox.h:110-120)
+// makes entry <= exit on every axis, and the pairwise rejects (bbox.h:124,133) together say that
+// every entry is <= every exit.  Here each quotient (plane - origin) / dir is replaced by
+// (plane - origin) * y, y = refined_rcp(dir): relative error below 2^-22, same sign, zero exactly
+// when the numerator is zero.  So HI >= 0 is decided exactly, and LO <= HI is decided exactly
+// whenever the two approximations are further apart than 2^-20 of their magnitudes; otherwise the
+// lane reports `ambiguous` and the caller runs the exact test.  `tnear` is the approximate LO
+// (ordering and culling only, inside the guard band of cull_limit).
+constexpr float SLAB_AMBIGUITY = 0x1p-20f;
+__device__ __forceinline__ bool slab_test_approx(float minx, float miny, float minz, float maxx, float maxy, float maxz, const Ray3& r, const RayInv& inv,
+                                                 float& tnear, bool& ambiguous) {
+	const float ax = (minx - r.ox) * inv.yx, bx = (maxx - r.ox) * inv.yx;
+	const float ay = (miny - r.oy) * inv.yy, by = (maxy - r.oy) * inv.yy;
+	const float az = (minz - r.oz) * inv.yz, bz = (maxz - r.oz) * inv.yz;
+	const float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+	const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+	ambiguous = fabsf(hi - lo) <= SLAB_AMBIGUITY * (fabsf(lo) + fabsf(hi));
+	tnear = lo;
+	return lo <= hi && hi >= 0.0f;
+}
+
 // Triangle::hit -- pathtracer/tri_mesh.cpp:46-111, on triangle data already in registers
 // (a = v0, b = e1, c = e2).
 __device__ __forceinline__ bool triangle_test(const float4 a, const float4 b, const float4 c, const Ray3& r, float& distance, float& t_out,
@@ -229,8 +254,19 @@ __device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const
 	if (STATS) stats->nodes++;
 	if (STATS) stats->max_sp = max(stats->max_sp, uint32_t(sp - base));
 	float tl, tr;
-	const bool hl = slab_test<FAST>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl);
-	const bool hr = slab_test<FAST>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr);
+	bool hl, hr;
+	if (FAST && MODE == MODE_CULLED) {
+		bool al, ar;
+		hl = slab_test_approx(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl, al);
+		hr = slab_test_approx(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr, ar);
+		if (__builtin_expect(__any(al || ar), 0)) {   // a ray grazing a box within rounding: decide it exactly
+			if (al) hl = slab_test<true>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl);
+			if (ar) hr = slab_test<true>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr);
+		}
+	} else {
+		hl = slab_test<FAST>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl);
+		hr = slab_test<FAST>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr);
+	}
 	if (MODE == MODE_REFERENCE) {
 		if (hl) {
 			if (hr) st.push(sp++, kids.y);

@@ -97,7 +97,7 @@ def render_leg(name, w, h, spp, depth, rank, world, dev, dist):
     wall = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        wt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        wt = torch.tensor([wall], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(wt, op=dist.ReduceOp.MAX)
         wall = float(wt.item())
     assert int(smp.min().item()) == spp and int(smp.max().item()) == spp
@@ -115,25 +115,36 @@ def main():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-render", action="store_true", help="skip the render legs")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="run the multi-rank code path on fewer GPUs than ranks: gloo collectives, rank r on device r %% device_count (a functional check, not a measurement)")
     args = ap.parse_args()
 
     import torch
     from pathtracer_amd import abi, capi, synth
 
+    def note(msg):
+        print(f"[bench r{os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.rehearse:
+        local_rank = local_rank % torch.cuda.device_count()
     if args.gpus > 1 or world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         dist = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
 
+    note("process group ready" if dist is not None else "single process")
     # ---- workload: same scene on every rank, a different ray batch per rank
     verts, idx = synth.soup(args.tris)
     t0 = time.perf_counter()
@@ -151,6 +162,8 @@ def main():
     occ_ref = torch.empty(args.rays, dtype=torch.uint8, device=dev)
     occ = torch.empty(args.rays, dtype=torch.uint8, device=dev)
     n = args.rays
+
+    note(f"scene resident: {len(nodes)} nodes, build {build_s:.2f} s")
 
     def closest(mode, out):
         scene.trace_closest_device(rays, out, flags=mode | abi.PTX_ASYNC, n=n)
@@ -175,6 +188,8 @@ def main():
             json.dump({"rays": [int(b) for b in bad], "culled": hits[bad].cpu().numpy().tolist(), "reference": hits_ref[bad].cpu().numpy().tolist(),
                        "ray_data": rays_h[bad].view(np.float32).reshape(-1, 8).tolist()}, f)
 
+    note(f"parity of the culled order on {n} rays: {mismatch_closest} closest-hit and {mismatch_any} occlusion mismatches")
+
     def timed(fn, steps, warmup):
         for _ in range(warmup):
             fn()
@@ -193,7 +208,7 @@ def main():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
-            w = torch.tensor([wall], dtype=torch.float64, device=dev)
+            w = torch.tensor([wall], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(w, op=dist.ReduceOp.MAX)
             wall = float(w.item())
         return wall, e0.elapsed_time(e1) / steps   # whole-job wall seconds, per-launch device ms (HIP events)
@@ -206,6 +221,7 @@ def main():
     kt = scene.kernel_times_ms(min(64, args.steps))
     kernel_ms = float(kt.mean()) if len(kt) else step_ms
 
+    note(f"timed region done: {value:.1f} Mrays/s")
     # secondary figures (not part of `value`)
     _, ref_ms = timed(lambda: closest(abi.PTX_TRAVERSE_REFERENCE, hits_ref), max(1, args.steps // 3), 1)
     _, cul_ms = timed(lambda: closest(abi.PTX_TRAVERSE_CULLED, hits), max(1, args.steps // 3), 1)
@@ -214,7 +230,7 @@ def main():
     result = {
         "metric": "Mrays/sec closest-hit", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, gloo collectives -- not a measurement)" if args.rehearse else ""),
         "config": {"workload": f"config 3: {n} incoherent rays per GPU vs {args.tris}-triangle soup BVH (max_leaf 4), closest-hit (t, primitive id)",
                    "traversal": "culled" if headline_mode == abi.PTX_TRAVERSE_CULLED else "reference", "rays_per_gpu": n,
                    "triangles": args.tris, "bvh_nodes": int(len(nodes)), "bvh_build_s": round(build_s, 3)},
@@ -238,9 +254,10 @@ def main():
     if not args.no_render:
         for name, w, h, spp, depth, label in (("cbox", 256, 256, 16, 4, "config 1: cbox.js3d 256x256, 16 spp, depth 4"),
                                               ("refract_cow_cbox", 1024, 1024, 256, 8, "config 2: refract_cow_cbox.js3d 1024x1024, 256 spp, depth 8")):
+            note(f"render leg {name} {w}x{h} {spp} spp")
             paths, rwall, mean = render_leg(name, w, h, spp, depth, rank, world, dev, dist)
             renders.append({"workload": label, "paths": paths, "wall_s": round(rwall, 4), "Mspp_per_s": round(paths / rwall / 1e6, 2),
-                            "mean_radiance": round(mean, 5), "frame_reduce": "rccl all_reduce int64+int32" if world > 1 else "none"})
+                            "mean_radiance": round(mean, 5), "frame_reduce": (("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) + " all_reduce int64+int32") if world > 1 else "none"})
     result["renders"] = renders
 
     if rank == 0:

@@ -17,7 +17,10 @@
 
 namespace ptx {
 
-constexpr uint32_t SORT_GRID_BITS = 5;                                    // 32 cells per axis
+#ifndef PTX_SORT_GRID_BITS
+#define PTX_SORT_GRID_BITS 5
+#endif
+constexpr uint32_t SORT_GRID_BITS = PTX_SORT_GRID_BITS;                   // 32 cells per axis
 constexpr uint32_t SORT_BUCKETS = 1u << (3 * SORT_GRID_BITS + 3);         // 262144
 constexpr uint32_t SCAN_THREADS = 1024;
 

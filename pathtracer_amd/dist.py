@@ -34,8 +34,16 @@ def reduce_frame(accum, samples, group=None):
     import torch.distributed as dist
     assert accum.dtype == torch.int64 and samples.dtype == torch.int32
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(samples, op=dist.ReduceOp.SUM, group=group)
+        if accum.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo is the CPU rehearsal backend: stage device tensors through host memory
+            a, s = accum.cpu(), samples.cpu()
+            dist.all_reduce(a, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+            accum.copy_(a)
+            samples.copy_(s)
+        else:
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(samples, op=dist.ReduceOp.SUM, group=group)
     return accum, samples
 
 

@@ -35,6 +35,23 @@ __global__ void __launch_bounds__(256) k_gather(const float4* __restrict__ table
 		if (MODE == 0) {
 			const float4* p = table + size_t(idx) * 4;
 			q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+		} else if (MODE == 3) {
+			// quad-cooperative LDS-DMA: instruction j brings the records of lanes 16j..16j+15, one quad per
+			// record, one quarter per lane; the quarter order is XOR-swizzled on the source side so that
+			// the readers (one record per lane, stride 64 B) hit distinct banks
+			__attribute__((address_space(3))) char* wave_lds = (__attribute__((address_space(3))) char*)lds + wave_base * 64;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const uint32_t S = 16u * j + (lane >> 2);
+				const uint32_t iS = __shfl(idx, S);
+				const char* src = reinterpret_cast<const char*>(table + size_t(iS) * 4) + 16u * ((lane & 3u) ^ ((S >> 2) & 3u));
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), wave_lds + j * 1024, 16, 0, 0);
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			const float4* rd = lds + (wave_base + lane) * 4;
+			const uint32_t sw = (lane >> 2) & 3u;
+			q0 = rd[0 ^ sw], q1 = rd[1 ^ sw], q2 = rd[2 ^ sw], q3 = rd[3 ^ sw];
+			__builtin_amdgcn_wave_barrier();
 		} else {
 			const uint32_t quad = lane & ~3u, k = lane & 3u;
 			const uint32_t i0 = __shfl(idx, quad | 0), i1 = __shfl(idx, quad | 1), i2 = __shfl(idx, quad | 2), i3 = __shfl(idx, quad | 3);
@@ -76,12 +93,13 @@ int main(int argc, char** argv) {
 	CHECK(hipEventCreate(&e0));
 	CHECK(hipEventCreate(&e1));
 	std::vector<uint32_t> r0(blocks * 256), r1(blocks * 256);
-	for (int mode = 0; mode < 3; mode++) {
+	for (int mode = 0; mode < 4; mode++) {
 		float best = 1e9f;
 		for (int rep = 0; rep < 3; rep++) {
 			CHECK(hipEventRecord(e0));
 			if (mode == 0) hipLaunchKernelGGL(k_gather<0>, dim3(blocks), dim3(256), 0, 0, d, n, iters, out);
 			if (mode == 1) hipLaunchKernelGGL(k_gather<1>, dim3(blocks), dim3(256), 0, 0, d, n, iters, out);
+			if (mode == 3) hipLaunchKernelGGL(k_gather<3>, dim3(blocks), dim3(256), 0, 0, d, n, iters, out);
 			if (mode == 2) hipLaunchKernelGGL(k_gather<2>, dim3(blocks), dim3(256), 0, 0, d, n, iters, out);
 			CHECK(hipEventRecord(e1));
 			CHECK(hipEventSynchronize(e1));
@@ -92,7 +110,7 @@ int main(int argc, char** argv) {
 		CHECK(hipMemcpy((mode == 0 ? r0 : r1).data(), out, blocks * 256 * 4, hipMemcpyDeviceToHost));
 		const double records = double(blocks) * 256 * iters;
 		std::printf("mode %d: %.3f ms, %.1f G records/s, %.1f GB/s%s\n", mode, best, records / best / 1e6, records * 64 / best / 1e6,
-		            mode == 1 ? (r0 == r1 ? "  (results equal mode 0)" : "  (RESULTS DIFFER)") : "");
+		            (mode == 1 || mode == 3) ? (r0 == r1 ? "  (results equal mode 0)" : "  (RESULTS DIFFER)") : "");
 	}
 	return 0;
 }

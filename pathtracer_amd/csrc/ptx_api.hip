@@ -13,6 +13,7 @@
 #include "host_math.h"
 #include "scene.h"
 #include "persistent.hip.h"
+#include "scene_persistent.hip.h"
 #include "raysort.hip.h"
 #include "traverse.hip.h"
 
@@ -360,7 +361,7 @@ static void mat_copy(float* dst, const float* src) { std::memcpy(dst, src, 16 * 
 // Single-mesh scenes whose tree is tame run on the persistent kernel (persistent.hip.h).
 static bool use_persistent(const PtxScene* s) { return s->rec.mesh_only && s->persistent_ok; }
 
-static int grow_scratch(PtxScene* s, int slot, size_t bytes) {
+int scene_scratch(PtxScene* s, int slot, size_t bytes) {
 	if (s->scratch_bytes[slot] >= bytes) return PTX_OK;
 	if (s->scratch[slot]) PTX_HIP(hipFree(s->scratch[slot]));
 	s->scratch[slot] = nullptr, s->scratch_bytes[slot] = 0;
@@ -368,6 +369,17 @@ static int grow_scratch(PtxScene* s, int slot, size_t bytes) {
 	s->scratch_bytes[slot] = bytes;
 	return PTX_OK;
 }
+int scene_counter_block(PtxScene* s, unsigned long long** out) {
+	if (!s->next_ray) {
+		void* p = nullptr;
+		PTX_HIP(hipMalloc(&p, 256));
+		s->allocations.push_back(p);
+		s->next_ray = static_cast<unsigned long long*>(p);
+	}
+	*out = s->next_ray;
+	return PTX_OK;
+}
+static int grow_scratch(PtxScene* s, int slot, size_t bytes) { return scene_scratch(s, slot, bytes); }
 
 // Groups the batch by origin cell and direction octant (raysort.hip.h); *order receives the
 // device array of ray indices in that order.
@@ -398,12 +410,8 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const PtxRay* 
 	const uint32_t* order = nullptr;
 	if (sort && n >= (1u << 16) && n < (uint64_t(1) << 32))
 		if (int rc = sort_rays(s, d_rays, n, &order)) return rc;
-	if (!s->next_ray) {
-		void* p = nullptr;
-		PTX_HIP(hipMalloc(&p, 256));
-		s->allocations.push_back(p);
-		s->next_ray = static_cast<unsigned long long*>(p);
-	}
+	unsigned long long* counters = nullptr;
+	if (int rc = scene_counter_block(s, &counters)) return rc;
 	PTX_HIP(hipMemsetAsync(s->next_ray, 0, 256, s->stream));
 	if (n >= (uint64_t(1) << 32)) return fail(PTX_ERR_INVALID, "ray count too large for one launch");
 	if (int rc = grow_scratch(s, 7, n * sizeof(uint32_t))) return rc;   // rays deferred to the plain-division kernel
@@ -746,6 +754,8 @@ int ptx_trace_closest(ptx_scene_t s, const PtxRay* rays, uint64_t n, PtxHit* hit
 	} else if (s->rec.mesh_only) {
 		if (culled) hipLaunchKernelGGL((k_trace_closest<MODE_CULLED, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
 		else hipLaunchKernelGGL((k_trace_closest<MODE_REFERENCE, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
+	} else if (culled && scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && n < (uint64_t(1) << 32)) {
+		if (int rc = launch_scene_persistent(s, BatchIO{d_rays, n, d_hits, d_bary, d_inst}, n)) return rc;
 	} else {
 		if (culled) hipLaunchKernelGGL((k_trace_closest<MODE_CULLED, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
 		else hipLaunchKernelGGL((k_trace_closest<MODE_REFERENCE, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);

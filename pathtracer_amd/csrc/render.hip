@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "scene.h"
+#include "scene_persistent.hip.h"
 #include "shade.hip.h"
 #include "traverse.hip.h"
 
@@ -133,6 +134,34 @@ __global__ void __launch_bounds__(256) k_extend(SceneRec sc, RenderBuffers rb, c
 	out.prim = h.hit ? h.prim : 0xFFFFFFFFu, out.inst = h.inst;
 	rb.hits[2 * slot + which] = out;
 }
+
+// The same work as k_extend as a ray source / hit sink of k_scene_persistent: the main rays of
+// the active paths first (neighbouring pixels, the more coherent half), then their direct rays.
+struct RenderIO {
+	RenderBuffers rb;
+	const uint32_t* list;
+	const uint32_t* n_paths;
+	uint32_t rays_per_path;   // 1 right after raygen (camera rays only), else 2
+	__device__ __forceinline__ uint64_t count() const { return uint64_t(*n_paths) * rays_per_path; }
+	__device__ __forceinline__ void load(uint32_t out, Ray3& r) const {
+		const float4* rp = reinterpret_cast<const float4*>(rb.rays + out);
+		const float4 a = rp[0], b = rp[1];
+		r = Ray3{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	}
+	__device__ __forceinline__ bool fetch(uint64_t item, Ray3& r, uint32_t& out) const {
+		const uint32_t n = *n_paths;
+		const uint32_t which = item >= n ? 1u : 0u;
+		out = 2u * list[which ? item - n : item] + which;
+		load(out, r);
+		return true;
+	}
+	__device__ __forceinline__ void store(uint32_t out, const SceneHit& h) const {
+		HitRec o{};
+		o.distance = h.distance, o.t = h.t, o.u = h.u, o.v = h.v;
+		o.prim = h.hit ? h.prim : 0xFFFFFFFFu, o.inst = h.inst;
+		rb.hits[out] = o;
+	}
+};
 
 // What Pathtracer::trace needs of a Trace (trace.h:20-26) rebuilt from a HitRec.
 struct Surface {
@@ -376,6 +405,7 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		hipLaunchKernelGGL(k_init_slots, dim3(uint32_t(chunk.size())), dim3(256), 0, s->stream, d_tiles, cam->film_width, rb);
 
 		const dim3 block(256), grid_slots((ns + 255) / 256), grid_items((2 * uint64_t(ns) + 255) / 256);
+		const bool persistent = scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT);
 		for (uint32_t k = 0; k < max_samples; k++) {
 			PTX_HIP(hipMemsetAsync(rb.counts, 0, 256, s->stream));
 			hipLaunchKernelGGL(k_raygen, grid_slots, block, 0, s->stream, rb, ns, k, cr, key0, key1, rb.active[0], rb.counts + 0);
@@ -384,7 +414,11 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 			// vertex of depth 0 never scatters, so after D+1 rounds no path is alive and every
 			// direct ray (written in round r, used at the start of round r+1) has been consumed.
 			for (uint32_t round = 0; round <= cam->film_max_ray_depth; round++) {
-				hipLaunchKernelGGL(k_extend<MODE_CULLED>, grid_items, block, 0, s->stream, s->rec, rb, rb.active[cur], rb.counts + cur);
+				if (persistent) {
+					if (int rc = launch_scene_persistent(s, RenderIO{rb, rb.active[cur], rb.counts + cur, round == 0 ? 1u : 2u}, 2 * uint64_t(ns))) return rc;
+				} else {
+					hipLaunchKernelGGL(k_extend<MODE_CULLED>, grid_items, block, 0, s->stream, s->rec, rb, rb.active[cur], rb.counts + cur);
+				}
 				PTX_HIP(hipMemsetAsync(rb.counts + (cur ^ 1), 0, sizeof(uint32_t), s->stream));
 				hipLaunchKernelGGL(k_shade<MODE_CULLED>, grid_slots, block, 0, s->stream, s->rec, s->shade, rb, rb.active[cur], rb.counts + cur, key0, key1,
 				                   rb.active[cur ^ 1], rb.counts + (cur ^ 1));

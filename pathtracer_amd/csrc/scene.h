@@ -55,6 +55,14 @@ struct ShadeTables {
 
 }  // namespace ptx
 
+struct PtxScene;
+namespace ptx {
+// Grows (never shrinks) one of the scene's device scratch buffers.
+int scene_scratch(PtxScene* s, int slot, size_t bytes);
+// The scene's 256-byte block of device counters, allocated on first use.
+int scene_counter_block(PtxScene* s, unsigned long long** out);
+}  // namespace ptx
+
 struct PtxBvh {
 	ptx::HostBvh bvh;
 };

@@ -1,0 +1,326 @@
+// scene_persistent.hip.h -- closest-hit queries against a two-level scene (instances over meshes
+// and analytic spheres) with wave-level ray replenishment and phase parking.
+//
+// Aggregate::hit over BVH<Instance> (aggregate.h:41-43) -> Instance::hit (instance.h:32-40) ->
+// Tri_Mesh::hit / Shapes::Sphere::hit, in the culled order (nearest child first, subtrees beyond the
+// running closest hit skipped, order-free tie rules -- see traverse.hip.h).
+//
+// One ray per lane and one `while` loop per level leaves most lanes of a wave idle: the lanes
+// are at different levels, in different instances, some in leaves and some on interior nodes
+// (20 % of the lanes active on the Cornell-box scenes).  Here a wave is again a pool of 64
+// traversal slots refilled from a global counter, and a lane is always in exactly one state:
+//
+//   WALK   on an interior node of the top-level tree or of the current instance's mesh tree
+//          (same code for both: the lane's current ray, reciprocals, node array and running
+//          hit are whatever level it is on)
+//   LEAF   holds a parked triangle leaf of the current mesh (and may go on walking meanwhile)
+//   ENTER  stands on a top-level leaf: has to move into an instance (ray to object space,
+//          root box test or sphere test)
+//   EXIT   finished the current instance's tree: has to carry the hit back to world space
+//
+// Each loop iteration executes ONE of the four phases -- the one most lanes are ready for -- and
+// the lanes in other states wait their turn, so every phase's code runs with many lanes active.
+#pragma once
+#include <cstdlib>
+
+#include "scene.h"
+#include "traverse.hip.h"
+
+namespace ptx {
+
+constexpr int SCENE_LDS_SLOTS = 12;
+constexpr unsigned long long SCENE_WAVE_CHUNK = 128;
+constexpr int SCENE_REFILL_MIN_IDLE = 8;
+constexpr uint32_t SCENE_ITERATION_CAP = 1u << 24;   // per wave; ordinary launches stay below 2^20
+
+// Where rays come from and where hits go.  fetch() returns false for an item that carries no ray.
+struct BatchIO {   // ptx_trace_closest on a general scene
+	const PtxRay* rays;
+	uint64_t n;
+	PtxHit* hits;
+	float* bary;
+	uint32_t* inst;
+	__device__ __forceinline__ uint64_t count() const { return n; }
+	__device__ __forceinline__ bool fetch(uint64_t item, Ray3& r, uint32_t& out) const {
+		const float4* rp = reinterpret_cast<const float4*>(rays + item);
+		const float4 a = rp[0], b = rp[1];
+		r = Ray3{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+		out = uint32_t(item);
+		return true;
+	}
+	__device__ __forceinline__ void load(uint32_t out, Ray3& r) const {
+		const float4* rp = reinterpret_cast<const float4*>(rays + out);
+		const float4 a = rp[0], b = rp[1];
+		r = Ray3{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	}
+	__device__ __forceinline__ void store(uint32_t out, const SceneHit& h) const {
+		PtxHit o;
+		o.distance = h.distance, o.prim = h.hit ? h.prim : PTX_NO_HIT;
+		hits[out] = o;
+		if (bary) reinterpret_cast<float2*>(bary)[out] = h.hit ? make_float2(h.u, h.v) : make_float2(0.0f, 0.0f);
+		if (inst) inst[out] = h.hit ? h.inst : PTX_NO_HIT;
+	}
+};
+
+template<typename IO>
+__global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, unsigned long long* __restrict__ next_item, uint32_t* __restrict__ slow_list,
+                                                          uint32_t* __restrict__ slow_count) {
+	constexpr int MODE = MODE_CULLED;
+	const unsigned lane = threadIdx.x & 63u;
+	const unsigned long long lanes_below = (1ull << lane) - 1ull;
+	const uint64_t n_items = io.count();
+
+	__shared__ uint32_t lds_ref[SCENE_LDS_SLOTS * 256];
+	__shared__ float lds_tnear[SCENE_LDS_SLOTS * 256];
+	Stack spill;
+	LdsStack<SCENE_LDS_SLOTS, 256> st{lds_ref + threadIdx.x, lds_tnear + threadIdx.x, &spill};
+
+	bool have_ray = false;
+	uint32_t out_index = 0;
+	Ray3 wr{}, cr{};            // world ray; current ray (the world ray at the top level, the object-space ray inside an instance)
+	RayInv winv{}, cinv{};
+	uint32_t level = 0;         // 0: top-level tree, 1: inside instance `cur_inst`
+	uint32_t ref = REF_DONE;
+	uint32_t pend = 0u;         // parked triangle leaf (level 1 only)
+	int sp = 0, base = 0;       // base: stack height at which the current level's walk is finished
+	uint32_t cur_inst = 0, inst_k = 0;   // instance being visited; position within the top-level leaf `top_leaf`
+	uint32_t top_leaf = 0u;
+	const Node2* __restrict__ cnodes = sc.nodes + sc.top_node_base;
+	const TriGeom* __restrict__ ctris = sc.tris;
+	SceneHit best{};            // Aggregate-level running Trace
+	MeshHit mh{};               // running Trace of the current instance's mesh
+	bool pool_empty = false;
+	unsigned long long chunk_next = 0, chunk_end = 0;
+#ifdef PTX_PROFILE_LANES
+	unsigned long long prof[9] = {};
+#endif
+
+	// At the top level: skip empty leaves; a leaf with instances becomes the lane's `top_leaf`.
+	auto settle_top = [&]() {
+		while ((ref & REF_LEAF) && ref != REF_DONE && (ref & 15u) == 0u) pop_ref<MODE, false>(wr, st, 0, sp, ref, best.hit, best.distance);
+		if ((ref & REF_LEAF) && ref != REF_DONE) top_leaf = ref, inst_k = 0;
+	};
+	// The next instance of the current top-level leaf, or the next pending top-level subtree.
+	auto next_top = [&]() {
+		level = 0, cr = wr, cinv = winv, cnodes = sc.nodes + sc.top_node_base, base = 0;
+		inst_k++;
+		if (inst_k < (top_leaf & 15u)) {
+			ref = top_leaf;   // ENTER again, for the leaf's next instance
+		} else {
+			pop_ref<MODE, false>(wr, st, 0, sp, ref, best.hit, best.distance);
+			settle_top();
+		}
+	};
+	// Trace::min at the Aggregate level with the order-free tie rule (larger instance index wins a tie).
+	auto fold_world = [&](bool hit, float dist, float t, uint32_t prim, float u, float v) {
+		if (hit) {
+			const bool keep = best.hit && !(dist < best.distance || (dist == best.distance && cur_inst > best.inst));
+			if (!keep) best.hit = true, best.distance = dist, best.t = t, best.prim = prim, best.inst = cur_inst, best.u = u, best.v = v;
+		} else if (!best.hit) {
+			best.distance = 0.0f;   // Trace::min of two misses is a default Trace (trace.h:35)
+		}
+	};
+
+	// Exit condition every wave reaches: the pool runs dry and its lanes finish.  As a backstop against
+	// a scheduling mistake, a wave that has looped far longer than any workload needs hands its rays in
+	// flight, and whatever it still claims, to the plain kernel instead of walking them.
+	uint32_t iterations = 0;
+	bool bailed = false;
+	for (;;) {
+		if (++iterations == SCENE_ITERATION_CAP) {
+			bailed = true;
+			if (have_ray) slow_list[atomicAdd(slow_count, 1u)] = out_index;
+			have_ray = false, ref = REF_DONE, pend = 0u, level = 0u;
+		}
+		// ---- replenish dry slots
+		const unsigned long long dry = __ballot(!have_ray);
+		const int n_dry = __popcll(dry);
+		if (n_dry == 64 && pool_empty) break;
+		if (!pool_empty && n_dry >= SCENE_REFILL_MIN_IDLE) {
+			if (chunk_next >= chunk_end) {
+				unsigned long long b = 0;
+				if (lane == 0) b = atomicAdd(next_item, SCENE_WAVE_CHUNK);
+				b = __shfl(b, 0);
+				chunk_next = b, chunk_end = b + SCENE_WAVE_CHUNK < n_items ? b + SCENE_WAVE_CHUNK : n_items;
+				if (b >= n_items) chunk_next = chunk_end = n_items;
+			}
+			const unsigned long long b = chunk_next;
+			const unsigned long long take = (unsigned long long)n_dry < chunk_end - chunk_next ? (unsigned long long)n_dry : chunk_end - chunk_next;
+			chunk_next += take;
+			if (chunk_next >= n_items) pool_empty = true;
+			if (!have_ray) {
+				const uint64_t item = b + __popcll(dry & lanes_below);
+				if (item < b + take && io.fetch(item, wr, out_index)) {
+					if (!bailed && ray_in_fast_range(wr)) {
+						have_ray = true;
+						// Aggregate(BVH<Instance>)::hit starts from hit = false, distance = inf (bvh.cpp:257-259)
+						best.hit = false, best.distance = INFINITY, best.t = 0.0f, best.prim = 0xFFFFFFFFu, best.inst = 0xFFFFFFFFu, best.u = best.v = 0.0f;
+						winv.yx = refined_rcp(wr.dx), winv.yy = refined_rcp(wr.dy), winv.yz = refined_rcp(wr.dz);
+						level = 0, cr = wr, cinv = winv, cnodes = sc.nodes + sc.top_node_base, sp = 0, base = 0, pend = 0u;
+						float tn;
+						ref = slab_test<true>(sc.top_min[0], sc.top_min[1], sc.top_min[2], sc.top_max[0], sc.top_max[1], sc.top_max[2], wr, winv, tn) ? sc.top_ref : REF_DONE;
+						settle_top();
+					} else {
+						slow_list[atomicAdd(slow_count, 1u)] = out_index;   // finished by the one-ray-per-lane kernel with plain divisions
+					}
+				}
+			}
+		}
+
+		// ---- pick ONE phase for this iteration: the one most lanes are ready for.  Lanes in the other
+		// states wait (a waiting lane costs nothing; an instruction issued for a few lanes costs as much
+		// as one issued for all 64), so each phase's code runs with as many lanes as the wave can muster.
+		// a lane standing on a triangle leaf with its parking slot free parks it and takes its next
+		// pending subtree (empty leaves are dropped on the way)
+		while (have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE && pend == 0u) {
+			if (ref & 15u) pend = ref;
+			pop_ref<MODE, false>(cr, st, base, sp, ref, mh.hit, mh.distance);
+		}
+		const bool can_walk = have_ray && !(ref & REF_LEAF);
+		const bool has_parked = have_ray && pend != 0u;
+		const bool want_enter = have_ray && level == 0u && (ref & REF_LEAF) && ref != REF_DONE;
+		const bool want_exit = have_ray && level == 1u && ref == REF_DONE && pend == 0u;
+		const int n_walk = __popcll(__ballot(can_walk)), n_tri = __popcll(__ballot(has_parked));
+		const int n_enter = __popcll(__ballot(want_enter)), n_exit = __popcll(__ballot(want_exit));
+		const int n_max = max(max(n_walk, n_tri), max(n_enter, n_exit));
+#ifdef PTX_PROFILE_LANES
+		prof[0]++;
+#endif
+		if (n_max == 0) {
+			// nothing to execute: at most some lanes whose ray finished at once (it missed the scene's box)
+		} else if (n_walk == n_max) {
+			// ---- WALK: one box-test step on whichever tree the lane is in
+#ifdef PTX_PROFILE_LANES
+			prof[1]++, prof[2] += n_walk;
+#endif
+			if (can_walk) {
+				const bool run_hit = level ? mh.hit : best.hit;
+				const float run_dist = level ? mh.distance : best.distance;
+				node_step<MODE, false, true, false>(cnodes, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
+				if (level == 0u) settle_top();
+			}
+		} else if (n_tri == n_max) {
+			// ---- triangle phase: every parked leaf
+#ifdef PTX_PROFILE_LANES
+			prof[3]++, prof[4] += n_tri;
+#endif
+			if (has_parked) {
+				mesh_leaf<MODE, false, false>(ctris, (pend & REF_INDEX_MASK) >> 4, pend & 15u, cr, mh, nullptr);
+				pend = 0u;
+			}
+		} else if (n_exit == n_max) {
+			// ---- leave an instance: Instance::hit's tail (instance.h:36-39): Trace::transform(T, iT.T())
+			// recomputes the distance from the transformed hit point and origin (trace.h:38-43)
+#ifdef PTX_PROFILE_LANES
+			prof[5]++, prof[6] += n_exit;
+#endif
+			if (want_exit) {
+				const InstRec& in = sc.insts[cur_inst];
+				float dist = mh.distance;
+				if (mh.hit && in.has_transform) {
+					const float px = cr.ox + cr.dx * mh.t, py = cr.oy + cr.dy * mh.t, pz = cr.oz + cr.dz * mh.t;
+					float wx, wy, wz, qx, qy, qz;
+					mat_point(in.T, px, py, pz, wx, wy, wz);
+					mat_point(in.T, cr.ox, cr.oy, cr.oz, qx, qy, qz);
+					dist = norm3(wx - qx, wy - qy, wz - qz);
+				}
+				fold_world(mh.hit, dist, mh.t, mh.prim, mh.u, mh.v);
+				next_top();
+			}
+		} else {
+			// ---- enter an instance (instance.h:32-35): ray to object space, then the sphere test or the
+			// mesh's root box
+#ifdef PTX_PROFILE_LANES
+			prof[7]++, prof[8] += n_enter;
+#endif
+			if (want_enter) {
+				cur_inst = ((top_leaf & REF_INDEX_MASK) >> 4) + inst_k;
+				const InstRec& in = sc.insts[cur_inst];
+				Ray3 r = wr;
+				if (in.has_transform) r = ray_transform(in.iT, wr);
+				if (in.mesh < 0) {
+					float t;
+					const bool hit = sphere_test(in.radius, r, t);
+					float dist = t;
+					if (hit && in.has_transform) {
+						const float px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
+						float wx, wy, wz, qx, qy, qz;
+						mat_point(in.T, px, py, pz, wx, wy, wz);
+						mat_point(in.T, r.ox, r.oy, r.oz, qx, qy, qz);
+						dist = norm3(wx - qx, wy - qy, wz - qz);
+					}
+					fold_world(hit, dist, t, 0u, 0.0f, 0.0f);
+					next_top();
+				} else {
+					const MeshRec& mesh = sc.meshes[in.mesh];
+					if (mesh.is_list || !mesh.tame || !ray_in_fast_range(r)) {
+						// outside what this kernel handles exactly: hand the whole ray to the plain kernel
+						slow_list[atomicAdd(slow_count, 1u)] = out_index;
+						have_ray = false, ref = REF_DONE, pend = 0u, level = 0u;
+					} else {
+						// BVH<Triangle>::hit (bvh.cpp:246-270): running Trace starts at hit = false, distance = inf
+						mh.hit = false, mh.distance = INFINITY, mh.prim = 0xFFFFFFFFu, mh.t = 0.0f, mh.u = mh.v = 0.0f;
+						cr = r;
+						cinv.yx = refined_rcp(r.dx), cinv.yy = refined_rcp(r.dy), cinv.yz = refined_rcp(r.dz);
+						float tn;
+						if (slab_test<true>(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], cr, cinv, tn)) {
+							level = 1u, base = sp, ref = mesh.root_ref;
+							cnodes = sc.nodes + mesh.node_base, ctris = sc.tris + mesh.tri_base;
+						} else {
+							fold_world(false, 0.0f, 0.0f, 0u, 0.0f, 0.0f);
+							next_top();
+						}
+					}
+				}
+			}
+		}
+
+		if (have_ray && level == 0u && ref == REF_DONE) {
+			io.store(out_index, best);
+			have_ray = false;
+		}
+	}
+#ifdef PTX_PROFILE_LANES
+	if (lane == 0)
+		for (int k = 0; k < 9; k++) atomicAdd(next_item + 8 + k, prof[k]);
+#endif
+}
+
+// The rays k_scene_persistent set aside: one ray per lane, plain divisions, any scene.
+template<typename IO>
+__global__ void __launch_bounds__(256) k_scene_deferred(SceneRec sc, IO io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count) {
+	const uint32_t n = *count;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const uint32_t out = list[k];
+		Ray3 r;
+		io.load(out, r);
+		Stack st;
+		SceneHit h;
+		traverse_scene<MODE_CULLED, false>(sc, r, st, h);
+		io.store(out, h);
+	}
+}
+
+// ---- host side
+// The two-level kernel applies when the instance level is a tame tree; meshes it cannot handle
+// exactly (lists, untamed trees) send their rays to k_scene_deferred one by one.
+inline bool scene_persistent_ok(const PtxScene* s) { return !s->rec.mesh_only && !s->rec.top_is_list && s->rec.top_tame && s->rec.n_insts > 0; }
+
+template<typename IO>
+int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
+	unsigned long long* counters = nullptr;
+	if (int rc = scene_counter_block(s, &counters)) return rc;
+	if (int rc = scene_scratch(s, 7, size_t(max_items ? max_items : 1) * sizeof(uint32_t))) return rc;   // rays set aside for the plain kernel
+	uint32_t* slow_list = static_cast<uint32_t*>(s->scratch[7]);
+	uint32_t* slow_count = reinterpret_cast<uint32_t*>(counters) + 16;   // same zeroed block, its own 64-byte line
+	PTX_HIP(hipMemsetAsync(counters, 0, 256, s->stream));
+	// Tuning knobs for experiments (not part of the ABI).
+	static const int blocks_per_cu = getenv("PTX_SCENE_BLOCKS_PER_CU") ? atoi(getenv("PTX_SCENE_BLOCKS_PER_CU")) : 4;
+	const uint64_t want = (max_items + 255) / 256;
+	const dim3 block(256), grid(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu))))));
+	hipLaunchKernelGGL((k_scene_persistent<IO>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count);
+	hipLaunchKernelGGL((k_scene_deferred<IO>), dim3(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, 256)))), block, 0, s->stream, s->rec, io, slow_list, slow_count);
+	return PTX_OK;
+}
+
+}  // namespace ptx

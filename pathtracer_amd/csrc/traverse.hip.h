@@ -381,7 +381,10 @@ __device__ __forceinline__ void mat_point(const float* __restrict__ m, float x, 
 	const float ry = ((x * m[1] + y * m[5]) + z * m[9]) + 1.0f * m[13];
 	const float rz = ((x * m[2] + y * m[6]) + z * m[10]) + 1.0f * m[14];
 	const float rw = ((x * m[3] + y * m[7]) + z * m[11]) + 1.0f * m[15];
-	ox = rx / rw, oy = ry / rw, oz = rz / rw;
+	// project(): divide by w.  An affine matrix gives w == 1 exactly, and x / 1 == x in IEEE arithmetic,
+	// so the three divisions are skipped on that condition without changing a bit.
+	ox = rx, oy = ry, oz = rz;
+	if (rw != 1.0f) ox = rx / rw, oy = ry / rw, oz = rz / rw;
 }
 __device__ __forceinline__ void mat_rotate(const float* __restrict__ m, float x, float y, float z, float& ox, float& oy, float& oz) {
 	ox = ((x * m[0] + y * m[4]) + z * m[8]) + 0.0f * m[12];

@@ -405,7 +405,9 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		hipLaunchKernelGGL(k_init_slots, dim3(uint32_t(chunk.size())), dim3(256), 0, s->stream, d_tiles, cam->film_width, rb);
 
 		const dim3 block(256), grid_slots((ns + 255) / 256), grid_items((2 * uint64_t(ns) + 255) / 256);
-		const bool persistent = scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT);
+		// Small batches (a 256x256 film is 65k paths, 8 waves per CU) do not fill the replenishing kernel's
+		// waves for long enough to pay for its set-up launches: they keep one ray per lane.
+		const bool persistent = scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && ns >= (1u << 18);
 		for (uint32_t k = 0; k < max_samples; k++) {
 			PTX_HIP(hipMemsetAsync(rb.counts, 0, 256, s->stream));
 			hipLaunchKernelGGL(k_raygen, grid_slots, block, 0, s->stream, rb, ns, k, cr, key0, key1, rb.active[0], rb.counts + 0);

@@ -21,6 +21,7 @@
 // Each loop iteration executes ONE of the four phases -- the one most lanes are ready for -- and
 // the lanes in other states wait their turn, so every phase's code runs with many lanes active.
 #pragma once
+#include <cstdio>
 #include <cstdlib>
 
 #include "scene.h"
@@ -62,6 +63,8 @@ struct BatchIO {   // ptx_trace_closest on a general scene
 	}
 };
 
+// 117 VGPRs: four waves per SIMD.  Forcing five or six by register limit spills the traversal state
+// to scratch and runs 1.6x / 3x slower (measured), so the allocation is left to the compiler.
 template<typename IO>
 __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, unsigned long long* __restrict__ next_item, uint32_t* __restrict__ slow_list,
                                                           uint32_t* __restrict__ slow_count) {
@@ -282,7 +285,7 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 	}
 #ifdef PTX_PROFILE_LANES
 	if (lane == 0)
-		for (int k = 0; k < 9; k++) atomicAdd(next_item + 8 + k, prof[k]);
+		for (int k = 0; k < 9; k++) atomicAdd(next_item + 16 + k, prof[k]);   // bytes 128.. of the counter block (0: item counter, 64: slow_count)
 #endif
 }
 
@@ -319,6 +322,20 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 	const uint64_t want = (max_items + 255) / 256;
 	const dim3 block(256), grid(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu))))));
 	hipLaunchKernelGGL((k_scene_persistent<IO>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count);
+#ifdef PTX_PROFILE_LANES
+	{
+		static unsigned long long tot[9] = {};
+		static int launches = 0;
+		unsigned long long h[32];
+		PTX_HIP(hipStreamSynchronize(s->stream));
+		PTX_HIP(hipMemcpy(h, counters, sizeof(h), hipMemcpyDeviceToHost));
+		for (int k = 0; k < 9; k++) tot[k] += h[16 + k];
+		if (++launches % 200 == 0)
+			std::fprintf(stderr, "[scene lanes] iterations %llu | walk %llu x %.1f | tri %llu x %.1f | exit %llu x %.1f | enter %llu x %.1f\n", tot[0], tot[1],
+			             double(tot[2]) / double(tot[1] ? tot[1] : 1), tot[3], double(tot[4]) / double(tot[3] ? tot[3] : 1), tot[5], double(tot[6]) / double(tot[5] ? tot[5] : 1), tot[7],
+			             double(tot[8]) / double(tot[7] ? tot[7] : 1));
+	}
+#endif
 	hipLaunchKernelGGL((k_scene_deferred<IO>), dim3(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, 256)))), block, 0, s->stream, s->rec, io, slow_list, slow_count);
 	return PTX_OK;
 }

@@ -61,11 +61,11 @@ def images(oracle, sb, cam, tiles):
     return capi.accumulator_to_image(acc_o, smp_o), capi.accumulator_to_image(acc_g, smp_g)
 
 
-def assert_same_stream(io, ig):
+def assert_same_stream(io, ig, rmse_rel=1e-3):
     d = np.abs(io - ig)
     rel = (d / np.maximum(np.abs(io), 1e-3)).max(axis=1)
     assert (rel <= 1e-3).mean() >= 0.995, f"{(rel > 1e-3).mean():.4f} of the pixels differ"
-    assert np.sqrt((d ** 2).mean()) <= 1e-3 * max(io.mean(), 1e-6)
+    assert np.sqrt((d ** 2).mean()) <= rmse_rel * max(io.mean(), 1e-6)
 
 
 @pytest.mark.parametrize("kind,use_bvh,fresnel", [
@@ -191,3 +191,26 @@ def test_image_gate_on_reference_scenes(name, mode, fresnel):
     rmse = float(np.sqrt(((got - ref_img) ** 2).mean()))
     assert rmse <= 1.5 * float(img["rmse_1024spp"]), (rmse, float(img["rmse_1024spp"]))
     np.testing.assert_allclose(got.mean(axis=0), img["mean"], rtol=0.03)
+
+
+def test_large_batch_replenishing_extend_is_bit_identical(oracle):
+    """Batches of >= 2^18 paths run the extend stage on the replenishing two-level kernel; smaller ones
+    (and PTX_NO_PERSISTENT) keep one ray per lane.  Scheduling differs, arithmetic does not: the two
+    accumulators are equal bit for bit, and both agree with the checker's same-stream render."""
+    sb = lit_scene("delta")
+    desc = sb.desc()
+    w = h = 512
+    spp = 2
+    cam = camera(w, h, spp, 4)
+    tiles = capi.make_tiles(w, h, spp, 21)
+    gsc = capi.Scene(desc, keep=sb)
+    acc_p, smp_p = gsc.render_tiles(cam, tiles, SEED)
+    acc_n, smp_n = gsc.render_tiles(cam, tiles, SEED, flags=abi.PTX_NO_PERSISTENT)
+    gsc.close()
+    assert (smp_p == spp).all() and (smp_n == spp).all()
+    assert (acc_p == acc_n).all()
+    osc = oracle.scene(desc)
+    acc_o, smp_o = osc.render_tiles(cam, tiles, 1, SEED)
+    osc.close()
+    # at 2 spp one sample that took another path (a last-bit difference in sin/cos/pow) moves its pixel by O(1): wider RMSE bound
+    assert_same_stream(capi.accumulator_to_image(acc_o, smp_o), capi.accumulator_to_image(acc_p, smp_p), rmse_rel=1e-2)

@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-render", action="store_true", help="skip the render legs")
+    ap.add_argument("--no-4k", action="store_true", help="skip the 3840x2160, 1024 spp render leg (about 30 s on one GPU)")
     ap.add_argument("--rehearse", action="store_true",
                     help="run the multi-rank code path on fewer GPUs than ranks: gloo collectives, rank r on device r %% device_count (a functional check, not a measurement)")
     args = ap.parse_args()
@@ -252,13 +253,20 @@ def main():
 
     renders = []
     if not args.no_render:
-        for name, w, h, spp, depth, label in (("cbox", 256, 256, 16, 4, "config 1: cbox.js3d 256x256, 16 spp, depth 4"),
-                                              ("refract_cow_cbox", 1024, 1024, 256, 8, "config 2: refract_cow_cbox.js3d 1024x1024, 256 spp, depth 8")):
+        legs = [("cbox", 256, 256, 16, 4, "config 1: cbox.js3d 256x256, 16 spp, depth 4"),
+                ("refract_cow_cbox", 1024, 1024, 256, 8, "config 2: refract_cow_cbox.js3d 1024x1024, 256 spp, depth 8")]
+        if not args.no_4k and not args.rehearse:
+            legs.append(("refract_cow_cbox", 3840, 2160, 1024, 8, "config 4: refract_cow_cbox.js3d 3840x2160, 1024 spp, depth 8, tiles dealt across the GPUs"))
+        for name, w, h, spp, depth, label in legs:
             note(f"render leg {name} {w}x{h} {spp} spp")
             paths, rwall, mean = render_leg(name, w, h, spp, depth, rank, world, dev, dist)
             renders.append({"workload": label, "paths": paths, "wall_s": round(rwall, 4), "Mspp_per_s": round(paths / rwall / 1e6, 2),
                             "mean_radiance": round(mean, 5), "frame_reduce": (("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) + " all_reduce int64+int32") if world > 1 else "none"})
     result["renders"] = renders
+    if len(renders) >= 2:
+        result["render_Mspp_per_s"] = renders[1]["Mspp_per_s"]     # config 2, the one-GPU render configuration
+    if len(renders) >= 3:
+        result["render_4k_Mspp_per_s"] = renders[2]["Mspp_per_s"]  # config 4, strong scaling across the GPUs
 
     if rank == 0:
         extra = {}

@@ -384,22 +384,38 @@ static int grow_scratch(PtxScene* s, int slot, size_t bytes) { return scene_scra
 // Groups the batch by origin cell and direction octant (raysort.hip.h); *order receives the
 // device array of ray indices in that order.
 static int sort_rays(PtxScene* s, const PtxRay* d_rays, uint64_t n, const uint32_t** order) {
-	if (int rc = grow_scratch(s, 4, n * sizeof(uint32_t))) return rc;               // keys
-	if (int rc = grow_scratch(s, 5, n * sizeof(uint32_t))) return rc;               // order
-	if (int rc = grow_scratch(s, 6, SORT_BUCKETS * sizeof(uint32_t))) return rc;    // histogram / offsets
-	uint32_t* keys = static_cast<uint32_t*>(s->scratch[4]);
-	uint32_t* ord = static_cast<uint32_t*>(s->scratch[5]);
-	uint32_t* hist = static_cast<uint32_t*>(s->scratch[6]);
+	const uint32_t n_tiles = uint32_t((n + SORT_TILE - 1) / SORT_TILE);
+	// digit-major table of per-tile counts, padded with zeros to whole scan chunks, then the chunk totals
+	const uint32_t n_chunks = (SORT_DIGITS * n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+	const uint32_t table_len = n_chunks * SCAN_CHUNK;
+	if (int rc = grow_scratch(s, 4, 2 * n * sizeof(uint32_t))) return rc;           // keys, keys after pass 0
+	if (int rc = grow_scratch(s, 5, 2 * n * sizeof(uint32_t))) return rc;           // indices after pass 0, final order
+	if (int rc = grow_scratch(s, 6, (size_t(table_len) + n_chunks) * sizeof(uint32_t))) return rc;
+	uint32_t* keys0 = static_cast<uint32_t*>(s->scratch[4]);
+	uint32_t* keys1 = keys0 + n;
+	uint32_t* idx1 = static_cast<uint32_t*>(s->scratch[5]);
+	uint32_t* ord = idx1 + n;
+	uint32_t* table = static_cast<uint32_t*>(s->scratch[6]);
+	uint32_t* totals = table + table_len;
+	auto scan = [&]() {
+		hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(256), 0, s->stream, table, totals);
+		hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(256), 0, s->stream, totals, n_chunks);
+		hipLaunchKernelGGL(k_scan_add, dim3(n_chunks), dim3(256), 0, s->stream, table, totals);
+	};
 	const PtxBvhNode& root = s->mesh_bvhs[0].nodes[0];
 	const float cells = float(1u << SORT_GRID_BITS);
 	float3 lo = make_float3(root.bmin[0], root.bmin[1], root.bmin[2]), scale;
 	const float ex = root.bmax[0] - root.bmin[0], ey = root.bmax[1] - root.bmin[1], ez = root.bmax[2] - root.bmin[2];
 	scale.x = ex > 0.0f ? cells / ex : 0.0f, scale.y = ey > 0.0f ? cells / ey : 0.0f, scale.z = ez > 0.0f ? cells / ez : 0.0f;
-	PTX_HIP(hipMemsetAsync(hist, 0, SORT_BUCKETS * sizeof(uint32_t), s->stream));
-	const dim3 block(256), grid(uint32_t((n + 255) / 256));
-	hipLaunchKernelGGL(k_sort_histogram, grid, block, 0, s->stream, d_rays, n, lo, scale, keys, hist);
-	hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SCAN_THREADS), 0, s->stream, hist);
-	hipLaunchKernelGGL(k_sort_scatter, grid, block, 0, s->stream, keys, n, hist, ord);
+	const dim3 block(256), grid(n_tiles);
+	const size_t pad = size_t(table_len) - size_t(SORT_DIGITS) * n_tiles;
+	if (pad) PTX_HIP(hipMemsetAsync(table + size_t(SORT_DIGITS) * n_tiles, 0, pad * sizeof(uint32_t), s->stream));
+	hipLaunchKernelGGL(k_sort_count_rays, grid, block, 0, s->stream, d_rays, n, lo, scale, keys0, table, n_tiles);
+	scan();
+	hipLaunchKernelGGL(k_sort_scatter<true>, grid, block, 0, s->stream, keys0, static_cast<const uint32_t*>(nullptr), n, table, n_tiles, keys1, idx1);
+	hipLaunchKernelGGL(k_sort_count_keys, grid, block, 0, s->stream, keys1, n, table, n_tiles);
+	scan();
+	hipLaunchKernelGGL(k_sort_scatter<false>, grid, block, 0, s->stream, keys1, idx1, n, table, n_tiles, static_cast<uint32_t*>(nullptr), ord);
 	*order = ord;
 	return PTX_OK;
 }

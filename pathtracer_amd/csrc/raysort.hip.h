@@ -1,4 +1,4 @@
-// raysort.hip.h -- bucket sort of a ray batch for coherence.
+// raysort.hip.h -- grouping of a ray batch for coherence.
 //
 // A wave advances only when the slowest of its 64 node fetches has come back, so with
 // incoherent rays every traversal step pays the latency of the farthest memory tier any
@@ -7,9 +7,16 @@
 // cache lines and stay in L1/L2.  This pass groups the batch that way before tracing:
 //   key = Morton code of the origin's cell on a 32^3 grid over the tree's root box (15 bits)
 //         followed by the direction's sign octant (3 bits)
-// and a counting sort (histogram, exclusive scan, scatter) produces `order`, the ray indices
-// grouped by key.  Only the order in which rays are picked up changes; every ray's result is
-// computed from that ray alone and written to its own slot, so results are unaffected.
+// and two radix passes of 9 bits each (low digit, then high digit) produce `order`, the ray
+// indices grouped by key.  Each pass is count -> scan -> scatter over tiles of SORT_TILE rays:
+// a block counts its tile's digits in an LDS histogram, a three-kernel scan turns the digit-major
+// table of all tiles' counts into offsets, and the scatter ranks every ray with an LDS atomic on its digit's
+// running offset.  The LDS rank is not stable inside a tile, so rays of one tile that share the
+// high digit can leave the second pass in another order than they entered it: the result is a
+// permutation grouped by the high digit and, within it, by the low digit up to a shuffle among
+// a tile's few dozen neighbours -- as good for coherence, and no atomics leave the CU.
+// Only the order in which rays are picked up changes; every ray's result is computed from
+// that ray alone and written to its own slot, so results are unaffected.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -17,12 +24,11 @@
 
 namespace ptx {
 
-#ifndef PTX_SORT_GRID_BITS
-#define PTX_SORT_GRID_BITS 5
-#endif
-constexpr uint32_t SORT_GRID_BITS = PTX_SORT_GRID_BITS;                   // 32 cells per axis
-constexpr uint32_t SORT_BUCKETS = 1u << (3 * SORT_GRID_BITS + 3);         // 262144
-constexpr uint32_t SCAN_THREADS = 1024;
+constexpr uint32_t SORT_GRID_BITS = 5;                     // 32 cells per axis
+constexpr uint32_t SORT_KEY_BITS = 3 * SORT_GRID_BITS + 3; // 18
+constexpr uint32_t SORT_DIGIT_BITS = 9, SORT_DIGITS = 1u << SORT_DIGIT_BITS;
+constexpr uint32_t SORT_TILE = 16384;                      // rays per block and pass
+static_assert(SORT_KEY_BITS == 2 * SORT_DIGIT_BITS, "two passes cover the key");
 
 __device__ __forceinline__ uint32_t spread3(uint32_t v) {   // 5 bits -> every third bit
 	v &= 0x1Fu;
@@ -42,47 +48,110 @@ __device__ __forceinline__ uint32_t ray_sort_key(const PtxRay& r, float3 lo, flo
 	return ((spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2)) << 3) | octant;
 }
 
-__global__ void __launch_bounds__(256) k_sort_histogram(const PtxRay* __restrict__ rays, uint64_t n, float3 lo, float3 scale,
-                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ hist) {
-	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const float4* rp = reinterpret_cast<const float4*>(rays + i);
-	const float4 a = rp[0], b = rp[1];
-	PtxRay r{{a.x, a.y, a.z}, {a.w, b.x, b.y}, b.z, b.w};
-	const uint32_t k = ray_sort_key(r, lo, scale);
-	keys[i] = k;
-	atomicAdd(&hist[k], 1u);
-}
-
-// Exclusive scan of SORT_BUCKETS counters in place, one block.
-__global__ void __launch_bounds__(SCAN_THREADS) k_sort_scan(uint32_t* __restrict__ hist) {
-	__shared__ uint32_t partial[SCAN_THREADS];
-	constexpr uint32_t PER = SORT_BUCKETS / SCAN_THREADS;
-	const uint32_t t = threadIdx.x;
-	uint32_t sum = 0;
-	for (uint32_t k = 0; k < PER; k++) sum += hist[t * PER + k];
-	partial[t] = sum;
+// Pass 0 count: keys from the rays (stored for the later kernels) and the tile's low-digit histogram.
+__global__ void __launch_bounds__(256) k_sort_count_rays(const PtxRay* __restrict__ rays, uint64_t n, float3 lo, float3 scale, uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ table, uint32_t n_tiles) {
+	__shared__ uint32_t hist[SORT_DIGITS];
+	for (uint32_t d = threadIdx.x; d < SORT_DIGITS; d += blockDim.x) hist[d] = 0;
 	__syncthreads();
-	for (uint32_t step = 1; step < SCAN_THREADS; step <<= 1) {   // Hillis-Steele inclusive scan
-		const uint32_t add = t >= step ? partial[t - step] : 0u;
+	const uint64_t begin = uint64_t(blockIdx.x) * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
+	for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
+		const float4* rp = reinterpret_cast<const float4*>(rays + i);
+		const float4 a = rp[0], b = rp[1];
+		const PtxRay r{{a.x, a.y, a.z}, {a.w, b.x, b.y}, b.z, b.w};
+		const uint32_t k = ray_sort_key(r, lo, scale);
+		keys[i] = k;
+		atomicAdd(&hist[k & (SORT_DIGITS - 1u)], 1u);
+	}
+	__syncthreads();
+	for (uint32_t d = threadIdx.x; d < SORT_DIGITS; d += blockDim.x) table[size_t(d) * n_tiles + blockIdx.x] = hist[d];
+}
+
+// Pass 1 count: high-digit histogram of a tile of the first pass's output.
+__global__ void __launch_bounds__(256) k_sort_count_keys(const uint32_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ table, uint32_t n_tiles) {
+	__shared__ uint32_t hist[SORT_DIGITS];
+	for (uint32_t d = threadIdx.x; d < SORT_DIGITS; d += blockDim.x) hist[d] = 0;
+	__syncthreads();
+	const uint64_t begin = uint64_t(blockIdx.x) * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
+	for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&hist[keys[i] >> SORT_DIGIT_BITS], 1u);
+	__syncthreads();
+	for (uint32_t d = threadIdx.x; d < SORT_DIGITS; d += blockDim.x) table[size_t(d) * n_tiles + blockIdx.x] = hist[d];
+}
+
+// Exclusive scan of the table in place, three small kernels:
+//   k_scan_local   every block scans its own SCAN_CHUNK counters and publishes their total
+//   k_scan_totals  one block scans the chunk totals (a few hundred values for 16M rays)
+//   k_scan_add     every block adds its chunk's offset
+// The table's length is a multiple of SCAN_CHUNK (the caller pads it with zeros).
+constexpr uint32_t SCAN_CHUNK = 2048;   // 256 threads x 8 counters
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t value, uint32_t* lds /* 256 entries */, uint32_t& total) {
+	const uint32_t t = threadIdx.x;
+	lds[t] = value;
+	__syncthreads();
+	for (uint32_t step = 1; step < 256; step <<= 1) {   // Hillis-Steele inclusive scan
+		const uint32_t add = t >= step ? lds[t - step] : 0u;
 		__syncthreads();
-		partial[t] += add;
+		lds[t] += add;
 		__syncthreads();
 	}
-	uint32_t running = partial[t] - sum;
-	for (uint32_t k = 0; k < PER; k++) {
-		const uint32_t c = hist[t * PER + k];
-		hist[t * PER + k] = running;
-		running += c;
+	total = lds[255];
+	return lds[t] - value;
+}
+
+__global__ void __launch_bounds__(256) k_scan_local(uint32_t* __restrict__ table, uint32_t* __restrict__ totals) {
+	__shared__ uint32_t lds[256];
+	uint4* p = reinterpret_cast<uint4*>(table + size_t(blockIdx.x) * SCAN_CHUNK) + 2 * threadIdx.x;
+	uint4 a = p[0], b = p[1];
+	const uint32_t sum = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+	uint32_t total;
+	uint32_t run = block_exclusive_scan_256(sum, lds, total);
+	uint4 oa, ob;
+	oa.x = run, run += a.x, oa.y = run, run += a.y, oa.z = run, run += a.z, oa.w = run, run += a.w;
+	ob.x = run, run += b.x, ob.y = run, run += b.y, ob.z = run, run += b.z, ob.w = run;
+	p[0] = oa, p[1] = ob;
+	if (threadIdx.x == 0) totals[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) k_scan_totals(uint32_t* __restrict__ totals, uint32_t count) {
+	__shared__ uint32_t lds[256];
+	const uint32_t per = (count + 255) / 256, begin = threadIdx.x * per, end = begin + per < count ? begin + per : count;
+	uint32_t sum = 0;
+	for (uint32_t k = begin; k < end; k++) sum += totals[k];
+	uint32_t total;
+	uint32_t run = block_exclusive_scan_256(sum, lds, total);
+	for (uint32_t k = begin; k < end; k++) {
+		const uint32_t c = totals[k];
+		totals[k] = run;
+		run += c;
 	}
 }
 
-__global__ void __launch_bounds__(256) k_sort_scatter(const uint32_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ offsets,
-                                                      uint32_t* __restrict__ order) {
-	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const uint32_t pos = atomicAdd(&offsets[keys[i]], 1u);
-	order[pos] = uint32_t(i);
+__global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ table, const uint32_t* __restrict__ totals) {
+	const uint32_t add = totals[blockIdx.x];
+	uint4* p = reinterpret_cast<uint4*>(table + size_t(blockIdx.x) * SCAN_CHUNK) + 2 * threadIdx.x;
+	uint4 a = p[0], b = p[1];
+	a.x += add, a.y += add, a.z += add, a.w += add, b.x += add, b.y += add, b.z += add, b.w += add;
+	p[0] = a, p[1] = b;
+}
+
+// Scatter of one pass.  FIRST: values are the rays' own indices and keys travel along; else values
+// are the first pass's indices and only they are written (the final order).
+template<bool FIRST>
+__global__ void __launch_bounds__(256) k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ values_in, uint64_t n,
+                                                      const uint32_t* __restrict__ table, uint32_t n_tiles, uint32_t* __restrict__ keys_out,
+                                                      uint32_t* __restrict__ values_out) {
+	__shared__ uint32_t offset[SORT_DIGITS];
+	for (uint32_t d = threadIdx.x; d < SORT_DIGITS; d += blockDim.x) offset[d] = table[size_t(d) * n_tiles + blockIdx.x];
+	__syncthreads();
+	const uint64_t begin = uint64_t(blockIdx.x) * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
+	for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
+		const uint32_t k = keys_in[i];
+		const uint32_t d = FIRST ? (k & (SORT_DIGITS - 1u)) : (k >> SORT_DIGIT_BITS);
+		const uint32_t pos = atomicAdd(&offset[d], 1u);
+		if (FIRST) keys_out[pos] = k, values_out[pos] = uint32_t(i);
+		else values_out[pos] = values_in[i];
+	}
 }
 
 }  // namespace ptx

@@ -129,3 +129,38 @@ def test_errors_are_reported_not_fatal():
         capi.Scene(mesh_desc=sb.mesh_desc(verts, idx), device=4096, keep=sb)
     with pytest.raises(capi.PtxError, match="max_leaf_size"):
         capi.Scene(mesh_desc=sb.mesh_desc(verts, idx, max_leaf_size=64), keep=sb)
+
+
+def test_many_instances_bit_exact(oracle):
+    """216 rotated, scaled instances of one mesh plus spheres: a deep instance-level tree (BVH<Instance>, max leaf 1).
+    Closest hits in both orders equal the CPU checker's bit for bit."""
+    sb = abi.SceneBuilder()
+    ico = sb.add_mesh(*scenes.icosphere(2))
+    m = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.5, 0.5, 0.5)))
+    for ix in range(6):
+        for iy in range(6):
+            for iz in range(6):
+                k = ix + 6 * iy + 36 * iz
+                if k % 7 == 3:
+                    sb.add_instance(-1, m, scenes.trs((ix * 1.1, iy * 1.1, iz * 1.1), scale=(0.4, 0.4, 0.4)), sphere_radius=1.0)
+                else:
+                    sb.add_instance(ico, m, scenes.trs((ix * 1.1, iy * 1.1, iz * 1.1), axis=(1, 2, 3), deg=13.0 * k, scale=(0.45, 0.35 + 0.01 * ix, 0.5)))
+    desc = sb.desc()
+    g = np.random.Generator(np.random.Philox(key=77))
+    n = 1 << 16
+    rays = np.zeros(n, dtype=abi.RAY_DTYPE)
+    rays["o"] = (g.random((n, 3), dtype=np.float32) * 9 - 1.5).astype(np.float32)
+    d = g.standard_normal((n, 3))
+    rays["d"] = synth._unit_f32(d / np.linalg.norm(d, axis=1, keepdims=True))
+    rays["tmin"], rays["tmax"] = 0.0, np.inf
+    osc = oracle.scene(desc)
+    want = osc.trace_closest(rays)
+    osc.close()
+    sc = capi.Scene(desc, keep=sb)
+    for flags in (abi.PTX_TRAVERSE_REFERENCE, abi.PTX_TRAVERSE_CULLED, abi.PTX_TRAVERSE_CULLED | abi.PTX_NO_PERSISTENT):
+        got = sc.trace_closest(rays, flags=flags)
+        assert (bits(got["hits"]["distance"]) == bits(want["hits"]["distance"])).all()
+        assert (got["hits"]["prim"] == want["hits"]["prim"]).all()
+        assert (got["inst"] == want["inst"]).all()
+    sc.close()
+    assert (want["hits"]["prim"] != abi.PTX_NO_HIT).mean() > 0.3

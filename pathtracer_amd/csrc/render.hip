@@ -41,11 +41,11 @@ constexpr float RAY_MINIMUM_BOUND = 0.001f;   // pathtracer.cpp:17
 constexpr uint32_t FLAG_CAMERA = 1u, FLAG_HAS_DIRECT = 2u;
 constexpr uint64_t MAX_SLOTS_PER_CHUNK = 8u << 20;
 
-struct SlotInfo {
+struct alignas(16) SlotInfo {
 	uint32_t pixel, s_begin, s_count, pad;
 };
 
-struct PathState {            // 64 bytes per slot
+struct alignas(16) PathState {            // 64 bytes per slot
 	float T[3];               // throughput of the main ray's path so far
 	uint32_t depth;           // Ray::depth of the main ray
 	float L[3];               // radiance gathered so far
@@ -69,11 +69,38 @@ struct RenderBuffers {
 	uint32_t* counts;     // [0], [1]: sizes of active[0], active[1]
 };
 
+// Records move between registers and memory as whole 16-byte pieces (one vector load or store per
+// piece, adjacent lanes adjacent in memory) instead of one dword at a time.
+template<typename T>
+__device__ __forceinline__ T load_rec(const T* p) {
+	static_assert(sizeof(T) % 16 == 0, "whole 16-byte pieces");
+	union {
+		T v;
+		uint4 q[sizeof(T) / 16];
+	} u;
+	const uint4* src = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+	for (size_t i = 0; i < sizeof(T) / 16; i++) u.q[i] = src[i];
+	return u.v;
+}
+template<typename T>
+__device__ __forceinline__ void store_rec(T* p, const T& v) {
+	static_assert(sizeof(T) % 16 == 0, "whole 16-byte pieces");
+	union {
+		T v;
+		uint4 q[sizeof(T) / 16];
+	} u;
+	u.v = v;
+	uint4* dst = reinterpret_cast<uint4*>(p);
+#pragma unroll
+	for (size_t i = 0; i < sizeof(T) / 16; i++) dst[i] = u.q[i];
+}
+
 __global__ void __launch_bounds__(256) k_init_slots(const TileRec* __restrict__ tiles, uint32_t film_w, RenderBuffers rb) {
 	const TileRec t = tiles[blockIdx.x];
 	for (uint32_t p = threadIdx.x; p < t.w * t.h; p += blockDim.x) {
 		const uint32_t x = t.x_begin + p % t.w, y = t.y_begin + p / t.w;
-		rb.slots[t.slot_base + p] = SlotInfo{y * film_w + x, t.s_begin, t.s_count, 0};
+		store_rec(rb.slots + t.slot_base + p, SlotInfo{y * film_w + x, t.s_begin, t.s_count, 0});
 		rb.sums[t.slot_base + p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	}
 }
@@ -96,7 +123,7 @@ __global__ void __launch_bounds__(256) k_raygen(RenderBuffers rb, uint32_t n_slo
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
 	bool live = false;
 	if (slot < n_slots) {
-		const SlotInfo si = rb.slots[slot];
+		const SlotInfo si = load_rec(rb.slots + slot);
 		if (k < si.s_count) {
 			live = true;
 			PathRng rng;
@@ -109,8 +136,8 @@ __global__ void __launch_bounds__(256) k_raygen(RenderBuffers rb, uint32_t n_slo
 			ps.draws = rng.draws;
 			ps.flags = FLAG_CAMERA;
 			ps.sample = si.s_begin + k;
-			rb.paths[slot] = ps;
-			rb.rays[2 * slot] = PtxRay{{r.ox, r.oy, r.oz}, {r.dx, r.dy, r.dz}, r.tmin, r.tmax};
+			store_rec(rb.paths + slot, ps);
+			store_rec(rb.rays + 2 * slot, PtxRay{{r.ox, r.oy, r.oz}, {r.dx, r.dy, r.dz}, r.tmin, r.tmax});
 		}
 	}
 	wave_append(live, slot, out_list, out_count);
@@ -132,7 +159,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneRec sc, RenderBuffers rb, c
 	HitRec out{};
 	out.distance = h.distance, out.t = h.t, out.u = h.u, out.v = h.v;
 	out.prim = h.hit ? h.prim : 0xFFFFFFFFu, out.inst = h.inst;
-	rb.hits[2 * slot + which] = out;
+	store_rec(rb.hits + 2 * slot + which, out);
 }
 
 // The same work as k_extend as a ray source / hit sink of k_scene_persistent: the main rays of
@@ -159,7 +186,7 @@ struct RenderIO {
 		HitRec o{};
 		o.distance = h.distance, o.t = h.t, o.u = h.u, o.v = h.v;
 		o.prim = h.hit ? h.prim : 0xFFFFFFFFu, o.inst = h.inst;
-		rb.hits[out] = o;
+		store_rec(rb.hits + out, o);
 	}
 };
 
@@ -211,13 +238,13 @@ __global__ void __launch_bounds__(256) k_shade(SceneRec sc, ShadeTables sh, Rend
 	uint32_t slot = 0;
 	if (i < *count) {
 		slot = list[i];
-		PathState ps = rb.paths[slot];
+		PathState ps = load_rec(rb.paths + slot);
 		V3f T = v3(ps.T[0], ps.T[1], ps.T[2]), L = v3(ps.L[0], ps.L[1], ps.L[2]);
 
 		// ---- the direct ray traced last round: trace(rng, new_in_ray).first (pathtracer.cpp:71-76)
 		if (ps.flags & FLAG_HAS_DIRECT) {
-			const PtxRay dr = rb.rays[2 * slot + 1];
-			const HitRec dh = rb.hits[2 * slot + 1];
+			const PtxRay dr = load_rec(rb.rays + 2 * slot + 1);
+			const HitRec dh = load_rec(rb.hits + 2 * slot + 1);
 			V3f first = v3(0, 0, 0);
 			if (dh.prim == 0xFFFFFFFFu) {
 				first = env_radiance(sh, v3(dr.d[0], dr.d[1], dr.d[2]));   // pathtracer.cpp:129-136
@@ -230,8 +257,8 @@ __global__ void __launch_bounds__(256) k_shade(SceneRec sc, ShadeTables sh, Rend
 		}
 
 		// ---- the main ray
-		const PtxRay mr = rb.rays[2 * slot];
-		const HitRec mh = rb.hits[2 * slot];
+		const PtxRay mr = load_rec(rb.rays + 2 * slot);
+		const HitRec mh = load_rec(rb.hits + 2 * slot);
 		const V3f ray_o = v3(mr.o[0], mr.o[1], mr.o[2]), ray_d = v3(mr.d[0], mr.d[1], mr.d[2]);
 		const bool camera = ps.flags & FLAG_CAMERA;
 		ps.flags = 0;
@@ -273,7 +300,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneRec sc, ShadeTables sh, Rend
 					if (!sc1.specular) w = w / bsdf_pdf(m, out_dir);                                      // pdf(in_dir, out_dir): `in` = out_dir
 					const V3f Wd = T * w;
 					ps.Wd[0] = Wd.x, ps.Wd[1] = Wd.y, ps.Wd[2] = Wd.z;
-					rb.rays[2 * slot + 1] = PtxRay{{s.position.x, s.position.y, s.position.z}, {in_world.x, in_world.y, in_world.z}, RAY_MINIMUM_BOUND, INFINITY};
+					store_rec(rb.rays + 2 * slot + 1, PtxRay{{s.position.x, s.position.y, s.position.z}, {in_world.x, in_world.y, in_world.z}, RAY_MINIMUM_BOUND, INFINITY});
 					ps.flags |= FLAG_HAS_DIRECT;
 				}
 				// sample_indirect_lighting (pathtracer.cpp:81-124)
@@ -283,7 +310,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneRec sc, ShadeTables sh, Rend
 					V3f w = sc2.specular ? sc2.attenuation : bsdf_evaluate(sh, m, out_dir, s.u, s.v);
 					if (!sc2.specular) w = w / bsdf_pdf(m, out_dir);
 					T = T * w;
-					rb.rays[2 * slot] = PtxRay{{s.position.x, s.position.y, s.position.z}, {in_world.x, in_world.y, in_world.z}, RAY_MINIMUM_BOUND, INFINITY};
+					store_rec(rb.rays + 2 * slot, PtxRay{{s.position.x, s.position.y, s.position.z}, {in_world.x, in_world.y, in_world.z}, RAY_MINIMUM_BOUND, INFINITY});
 					ps.depth -= 1;
 				}
 				ps.draws = rng.draws;
@@ -292,7 +319,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneRec sc, ShadeTables sh, Rend
 		}
 		if (alive) {
 			ps.T[0] = T.x, ps.T[1] = T.y, ps.T[2] = T.z, ps.L[0] = L.x, ps.L[1] = L.y, ps.L[2] = L.z;
-			rb.paths[slot] = ps;
+			store_rec(rb.paths + slot, ps);
 		} else {
 			// `if (p.valid()) sample.at(px, py) += p;` (pathtracer.cpp:466-470); pdf of the camera sample is 1
 			if (finite3(L)) {
@@ -309,7 +336,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneRec sc, ShadeTables sh, Rend
 __global__ void __launch_bounds__(256) k_flush(RenderBuffers rb, uint32_t n_slots, unsigned long long* __restrict__ accum, uint32_t* __restrict__ samples) {
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot >= n_slots) return;
-	const SlotInfo si = rb.slots[slot];
+	const SlotInfo si = load_rec(rb.slots + slot);
 	const float4 sum = rb.sums[slot];
 	const float scale = float(1ll << 24);   // n.r * (1ll << 24ll): the integer converts to float
 	atomicAdd(&accum[size_t(si.pixel) * 3 + 0], (unsigned long long)(long long)(sum.x * scale));

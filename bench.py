@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the ray-query hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the one the north star's >= 1 Gray/s target is quoted on):
+Workload (the synthetic ray-batch configuration, the one the >= 1 Gray/s closest-hit target is quoted on):
 16,777,216 incoherent rays against a 1,000,000-triangle procedural soup whose BVH is built
 by the host builder (max_leaf_size 4).  One "step" is one closest-hit pass over the whole ray
 batch, inputs and outputs resident in HBM.  With --gpus N every rank traces its own batch of

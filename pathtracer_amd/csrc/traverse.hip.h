@@ -245,14 +245,11 @@ __device__ __forceinline__ void pop_ref(const Ray3& r, StackType& st, const int 
 	}
 }
 
-template<int MODE, bool ANY, bool FAST, bool STATS, typename StackType>
-__device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const Ray3& r, const RayInv& inv, StackType& st, const int base, int& sp,
-                                          uint32_t& ref, bool run_hit, float run_dist, TraverseStats* stats) {
-	const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
-	const float4 n0 = p[0], n1 = p[1], n2 = p[2];
-	const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
-	if (STATS) stats->nodes++;
-	if (STATS) stats->max_sp = max(stats->max_sp, uint32_t(sp - base));
+// The decision half of a traversal step, on node data already in registers: n0, n1, n2 are the node's
+// first three 16-byte pieces (left box, right box), kids its two child references.
+template<int MODE, bool ANY, bool FAST, typename StackType>
+__device__ __forceinline__ void node_decide(const float4 n0, const float4 n1, const float4 n2, const uint2 kids, const Ray3& r, const RayInv& inv, StackType& st,
+                                            const int base, int& sp, uint32_t& ref, bool run_hit, float run_dist) {
 	float tl, tr;
 	bool hl, hr;
 	if (FAST && MODE == MODE_CULLED) {
@@ -292,6 +289,17 @@ __device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const
 			pop_ref<MODE, ANY>(r, st, base, sp, ref, run_hit, run_dist);
 		}
 	}
+}
+
+template<int MODE, bool ANY, bool FAST, bool STATS, typename StackType>
+__device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const Ray3& r, const RayInv& inv, StackType& st, const int base, int& sp,
+                                          uint32_t& ref, bool run_hit, float run_dist, TraverseStats* stats) {
+	const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
+	const float4 n0 = p[0], n1 = p[1], n2 = p[2];
+	const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
+	if (STATS) stats->nodes++;
+	if (STATS) stats->max_sp = max(stats->max_sp, uint32_t(sp - base));
+	node_decide<MODE, ANY, FAST>(n0, n1, n2, kids, r, inv, st, base, sp, ref, run_hit, run_dist);
 }
 
 // A whole traversal: walk interior nodes until every lane of the wave holds a leaf (or is

@@ -134,10 +134,16 @@ __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxR
 			prof_iters++, prof_node_lanes += __popcll(on_node), prof_node_iters += on_node != 0ull, prof_busy += __popcll(__ballot(have_ray));
 #endif
 			if (on_node != 0ull) {
-				if (!(ref & REF_LEAF)) node_step<MODE, ANY, true, false>(nodes, r, inv, st, 0, sp, ref, cur.hit, cur.distance, nullptr);
+				if (!(ref & REF_LEAF)) {
+					const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
+					const float4 n0 = p[0], n1 = p[1], n2 = p[2];
+					const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
+					node_decide<MODE, ANY, true, true>(n0, n1, n2, kids, r, inv, st, 0, sp, ref, cur.hit, cur.distance);
+				}
 			}
-			if ((ref & REF_LEAF) && ref != REF_DONE && pend == 0u) {
-				if (ref & 15u) pend = ref;   // an empty leaf has nothing to test
+			// one pop loop for both reasons to pop: no child taken, or a leaf reached and parked
+			if ((ref & REF_LEAF) && ref != REF_DONE && (ref == REF_NONE || pend == 0u)) {
+				if (ref != REF_NONE && (ref & 15u)) pend = ref;   // an empty leaf has nothing to test
 				pop_ref<MODE, ANY>(r, st, 0, sp, ref, cur.hit, cur.distance);
 			}
 			// ---- triangle phase: when enough leaves are parked, or too many lanes cannot go on

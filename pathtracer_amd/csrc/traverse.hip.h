@@ -27,6 +27,7 @@ namespace ptx {
 constexpr int STACK_CAP = 64;            // traversal stack entries per lane
 constexpr float CULL_SCALE = 1.0001f;    // guard band of the culled modes (see ptx.h)
 constexpr float CULL_BIAS = 1e-7f;
+constexpr uint32_t REF_NONE = 0xFFFFFFFEu;   // transient: "take the next pending subtree" (see node_decide)
 constexpr uint32_t REF_DONE = 0xFFFFFFFFu;   // leaf-shaped sentinel (no real leaf has both flag bits, start 2^26-1 and count 15)
 
 enum TraverseMode { MODE_REFERENCE = 0, MODE_CULLED = 1 };
@@ -247,7 +248,9 @@ __device__ __forceinline__ void pop_ref(const Ray3& r, StackType& st, const int 
 
 // The decision half of a traversal step, on node data already in registers: n0, n1, n2 are the node's
 // first three 16-byte pieces (left box, right box), kids its two child references.
-template<int MODE, bool ANY, bool FAST, typename StackType>
+// DEFER_POP: when neither child is taken, leave REF_NONE in `ref` instead of popping, so that a caller
+// with other reasons to pop (a leaf it parks) runs one pop loop for all of them.
+template<int MODE, bool ANY, bool FAST, bool DEFER_POP = false, typename StackType>
 __device__ __forceinline__ void node_decide(const float4 n0, const float4 n1, const float4 n2, const uint2 kids, const Ray3& r, const RayInv& inv, StackType& st,
                                             const int base, int& sp, uint32_t& ref, bool run_hit, float run_dist) {
 	float tl, tr;
@@ -285,6 +288,8 @@ __device__ __forceinline__ void node_decide(const float4 n0, const float4 n1, co
 			ref = kids.x;
 		} else if (gr) {
 			ref = kids.y;
+		} else if (DEFER_POP) {
+			ref = REF_NONE;
 		} else {
 			pop_ref<MODE, ANY>(r, st, base, sp, ref, run_hit, run_dist);
 		}

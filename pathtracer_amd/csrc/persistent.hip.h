@@ -158,12 +158,8 @@ __global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxR
 				if (pend != 0u) {
 					const bool stop = mesh_leaf<MODE, ANY, false>(tris, (pend & REF_INDEX_MASK) >> 4, pend & 15u, r, cur, nullptr);
 					pend = 0u;
-					if (stop) {
-						ref = REF_DONE, sp = 0;
-					} else if ((ref & REF_LEAF) && ref != REF_DONE) {   // the leaf this lane was held up by
-						if (ref & 15u) pend = ref;
-						pop_ref<MODE, ANY>(r, st, 0, sp, ref, cur.hit, cur.distance);
-					}
+					if (stop) ref = REF_DONE, sp = 0;
+					// a lane that was held up by a second leaf parks it at the next iteration's pop site
 				}
 			}
 			if (ref == REF_DONE && pend == 0u && have_ray) store_result();

@@ -16,7 +16,7 @@
 
 namespace ptx {
 
-constexpr int REFILL_MIN_IDLE = 8;    // refill when at least this many of the 64 slots are dry
+constexpr int REFILL_MIN_IDLE = 20;   // refill when at least this many of the 64 slots are dry
 constexpr int TRI_MIN_LANES = 1;      // reference order: run the triangle step when at least this many lanes stand in a leaf
 constexpr int PARK_MIN_LANES = 32;    // culled order: run the triangle phase when this many lanes have a leaf parked ...
 constexpr int STUCK_MAX_LANES = 16;   // ... or this many lanes cannot go on walking until their parked leaf is tested

@@ -67,7 +67,7 @@ struct BatchIO {   // ptx_trace_closest on a general scene
 // to scratch and runs 1.6x / 3x slower (measured), so the allocation is left to the compiler.
 template<typename IO>
 __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, unsigned long long* __restrict__ next_item, uint32_t* __restrict__ slow_list,
-                                                          uint32_t* __restrict__ slow_count) {
+                                                          uint32_t* __restrict__ slow_count, const int refill_min) {
 	constexpr int MODE = MODE_CULLED;
 	const unsigned lane = threadIdx.x & 63u;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 		const unsigned long long dry = __ballot(!have_ray);
 		const int n_dry = __popcll(dry);
 		if (n_dry == 64 && pool_empty) break;
-		if (!pool_empty && n_dry >= SCENE_REFILL_MIN_IDLE) {
+		if (!pool_empty && n_dry >= refill_min) {
 			if (chunk_next >= chunk_end) {
 				unsigned long long b = 0;
 				if (lane == 0) b = atomicAdd(next_item, SCENE_WAVE_CHUNK);
@@ -319,9 +319,10 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 	PTX_HIP(hipMemsetAsync(counters, 0, 256, s->stream));
 	// Tuning knobs for experiments (not part of the ABI).
 	static const int blocks_per_cu = getenv("PTX_SCENE_BLOCKS_PER_CU") ? atoi(getenv("PTX_SCENE_BLOCKS_PER_CU")) : 4;
+	static const int refill_min = getenv("PTX_SCENE_REFILL_MIN_IDLE") ? atoi(getenv("PTX_SCENE_REFILL_MIN_IDLE")) : SCENE_REFILL_MIN_IDLE;
 	const uint64_t want = (max_items + 255) / 256;
 	const dim3 block(256), grid(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu))))));
-	hipLaunchKernelGGL((k_scene_persistent<IO>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count);
+	hipLaunchKernelGGL((k_scene_persistent<IO>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count, refill_min);
 #ifdef PTX_PROFILE_LANES
 	{
 		static unsigned long long tot[9] = {};

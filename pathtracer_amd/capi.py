@@ -174,7 +174,11 @@ class Scene:
             lib().ptx_scene_destroy(self.h)
             self.h = vp()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except TypeError:
+            pass   # interpreter shutdown: module globals are already gone and the process's exit frees the scene
 
     def set_stream(self, stream_handle):
         check(lib().ptx_scene_set_stream(self.h, stream_handle))

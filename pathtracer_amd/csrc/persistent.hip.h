@@ -26,8 +26,10 @@ constexpr int STUCK_MAX_LANES = 16;   // ... or this many lanes cannot go on wal
 constexpr int PERSISTENT_LDS_SLOTS = PTX_LDS_SLOTS;   // stack entries per lane kept in LDS (8 B each)
 constexpr unsigned long long WAVE_CHUNK = 256;    // consecutive ray slots a wave claims at a time
 
+// The culled-order instance needs 82 VGPRs left alone, two above the 80 that let six waves share a
+// SIMD; held to 80 it runs 2 % faster on grouped rays (measured), the few spilled values being cold.
 template<int MODE, bool ANY>
-__global__ void __launch_bounds__(256) k_mesh_persistent(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, PtxHit* __restrict__ hits,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_mesh_persistent(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, PtxHit* __restrict__ hits,
                                                          float* __restrict__ bary, uint32_t* __restrict__ inst, uint8_t* __restrict__ occluded,
                                                          unsigned long long* __restrict__ next_ray, const int refill_min_idle,
                                                          const uint32_t* __restrict__ order, uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count,

@@ -29,7 +29,7 @@
 
 namespace ptx {
 
-constexpr int SCENE_LDS_SLOTS = 12;
+constexpr int SCENE_LDS_SLOTS = 8;
 constexpr unsigned long long SCENE_WAVE_CHUNK = 128;
 constexpr int SCENE_REFILL_MIN_IDLE = 8;
 constexpr uint32_t SCENE_ITERATION_CAP = 1u << 24;   // per wave; ordinary launches stay below 2^20
@@ -63,10 +63,12 @@ struct BatchIO {   // ptx_trace_closest on a general scene
 	}
 };
 
-// 117 VGPRs: four waves per SIMD.  Forcing five or six by register limit spills the traversal state
-// to scratch and runs 1.6x / 3x slower (measured), so the allocation is left to the compiler.
+// Registers, not LDS, decide how many waves share a SIMD here.  With the world ray (while the lane is
+// inside an instance) and the once-per-ray bookkeeping kept in LDS the kernel fits 96 VGPRs without
+// spilling: five waves per SIMD, five 31 KB blocks per CU.  (At the 117 VGPRs of the all-in-registers
+// version only four fit; the same render took 11 % longer.)
 template<typename IO>
-__global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, unsigned long long* __restrict__ next_item, uint32_t* __restrict__ slow_list,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_scene_persistent(SceneRec sc, IO io, unsigned long long* __restrict__ next_item, uint32_t* __restrict__ slow_list,
                                                           uint32_t* __restrict__ slow_count, const int refill_min) {
 	constexpr int MODE = MODE_CULLED;
 	const unsigned lane = threadIdx.x & 63u;
@@ -79,18 +81,24 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 	LdsStack<SCENE_LDS_SLOTS, 256> st{lds_ref + threadIdx.x, lds_tnear + threadIdx.x, &spill};
 
 	bool have_ray = false;
-	uint32_t out_index = 0;
-	Ray3 wr{}, cr{};            // world ray; current ray (the world ray at the top level, the object-space ray inside an instance)
-	RayInv winv{}, cinv{};
+	// Per-lane values touched once or twice per ray wait in LDS, not in registers: where the ray's
+	// result goes, the top-level leaf being worked through while the lane is inside one of its
+	// instances, and the payload of the best hit so far (only its distance steers the walk).
+	__shared__ uint32_t lds_ledger[7 * 256];
+	uint32_t* const ledger = lds_ledger + threadIdx.x;
+	enum { L_OUT = 0, L_TOP_LEAF = 256, L_T = 2 * 256, L_PRIM = 3 * 256, L_INST = 4 * 256, L_U = 5 * 256, L_V = 6 * 256 };
+	// Current ray: the world ray at the top level, the object-space ray inside an instance (the world
+	// ray then waits in LDS: registers, not LDS, limit how many waves fit a SIMD here).
+	Ray3 cr{};
+	RayInv cinv{};
+	__shared__ float4 lds_world_ray[2 * 256];
 	uint32_t level = 0;         // 0: top-level tree, 1: inside instance `cur_inst`
 	uint32_t ref = REF_DONE;
 	uint32_t pend = 0u;         // parked triangle leaf (level 1 only)
 	int sp = 0, base = 0;       // base: stack height at which the current level's walk is finished
-	uint32_t cur_inst = 0, inst_k = 0;   // instance being visited; position within the top-level leaf `top_leaf`
-	uint32_t top_leaf = 0u;
-	const Node2* __restrict__ cnodes = sc.nodes + sc.top_node_base;
-	const TriGeom* __restrict__ ctris = sc.tris;
-	SceneHit best{};            // Aggregate-level running Trace
+	uint32_t cnode_base = sc.top_node_base, ctri_base = 0u;   // current tree's first node / first triangle in the scene-wide arrays
+	bool best_hit = false;      // Aggregate-level running Trace: hit flag and distance (the rest is in the ledger)
+	float best_distance = 0.0f;
 	MeshHit mh{};               // running Trace of the current instance's mesh
 	bool pool_empty = false;
 	unsigned long long chunk_next = 0, chunk_end = 0;
@@ -98,29 +106,37 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 	unsigned long long prof[9] = {};
 #endif
 
-	// At the top level: skip empty leaves; a leaf with instances becomes the lane's `top_leaf`.
+	// At the top level a leaf reference names the instance to visit next (its first) and how many of the
+	// leaf's instances are left, that one included.  Empty leaves are skipped.
 	auto settle_top = [&]() {
-		while ((ref & REF_LEAF) && ref != REF_DONE && (ref & 15u) == 0u) pop_ref<MODE, false>(wr, st, 0, sp, ref, best.hit, best.distance);
-		if ((ref & REF_LEAF) && ref != REF_DONE) top_leaf = ref, inst_k = 0;
+		while ((ref & REF_LEAF) && ref != REF_DONE && (ref & 15u) == 0u) pop_ref<MODE, false>(cr, st, 0, sp, ref, best_hit, best_distance);
 	};
-	// The next instance of the current top-level leaf, or the next pending top-level subtree.
-	auto next_top = [&]() {
-		level = 0, cr = wr, cinv = winv, cnodes = sc.nodes + sc.top_node_base, base = 0;
-		inst_k++;
-		if (inst_k < (top_leaf & 15u)) {
-			ref = top_leaf;   // ENTER again, for the leaf's next instance
+	// The next instance of the top-level leaf `leaf`, or the next pending top-level subtree.
+	auto next_top = [&](uint32_t leaf) {
+		if (level == 1u) {   // back from an instance: the world ray returns from LDS
+			const float4 a = lds_world_ray[threadIdx.x], b = lds_world_ray[256 + threadIdx.x];
+			cr = Ray3{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+			cinv.yx = refined_rcp(cr.dx), cinv.yy = refined_rcp(cr.dy), cinv.yz = refined_rcp(cr.dz);
+		}
+		level = 0, cnode_base = sc.top_node_base, base = 0;
+		if ((leaf & 15u) > 1u) {
+			ref = leaf + 15u;   // first + 1, count - 1: ENTER again, for the leaf's next instance
 		} else {
-			pop_ref<MODE, false>(wr, st, 0, sp, ref, best.hit, best.distance);
+			pop_ref<MODE, false>(cr, st, 0, sp, ref, best_hit, best_distance);
 			settle_top();
 		}
 	};
 	// Trace::min at the Aggregate level with the order-free tie rule (larger instance index wins a tie).
-	auto fold_world = [&](bool hit, float dist, float t, uint32_t prim, float u, float v) {
+	auto fold_world = [&](uint32_t inst, bool hit, float dist, float t, uint32_t prim, float u, float v) {
 		if (hit) {
-			const bool keep = best.hit && !(dist < best.distance || (dist == best.distance && cur_inst > best.inst));
-			if (!keep) best.hit = true, best.distance = dist, best.t = t, best.prim = prim, best.inst = cur_inst, best.u = u, best.v = v;
-		} else if (!best.hit) {
-			best.distance = 0.0f;   // Trace::min of two misses is a default Trace (trace.h:35)
+			bool keep = best_hit && !(dist < best_distance);
+			if (keep && dist == best_distance) keep = !(inst > ledger[L_INST]);
+			if (!keep) {
+				best_hit = true, best_distance = dist;
+				ledger[L_T] = __float_as_uint(t), ledger[L_PRIM] = prim, ledger[L_INST] = inst, ledger[L_U] = __float_as_uint(u), ledger[L_V] = __float_as_uint(v);
+			}
+		} else if (!best_hit) {
+			best_distance = 0.0f;   // Trace::min of two misses is a default Trace (trace.h:35)
 		}
 	};
 
@@ -132,7 +148,7 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 	for (;;) {
 		if (++iterations == SCENE_ITERATION_CAP) {
 			bailed = true;
-			if (have_ray) slow_list[atomicAdd(slow_count, 1u)] = out_index;
+			if (have_ray) slow_list[atomicAdd(slow_count, 1u)] = ledger[L_OUT];
 			have_ray = false, ref = REF_DONE, pend = 0u, level = 0u;
 		}
 		// ---- replenish dry slots
@@ -153,15 +169,18 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 			if (chunk_next >= n_items) pool_empty = true;
 			if (!have_ray) {
 				const uint64_t item = b + __popcll(dry & lanes_below);
-				if (item < b + take && io.fetch(item, wr, out_index)) {
-					if (!bailed && ray_in_fast_range(wr)) {
+				uint32_t out_index;
+				if (item < b + take && io.fetch(item, cr, out_index)) {
+					if (!bailed && ray_in_fast_range(cr)) {
 						have_ray = true;
+						ledger[L_OUT] = out_index;
 						// Aggregate(BVH<Instance>)::hit starts from hit = false, distance = inf (bvh.cpp:257-259)
-						best.hit = false, best.distance = INFINITY, best.t = 0.0f, best.prim = 0xFFFFFFFFu, best.inst = 0xFFFFFFFFu, best.u = best.v = 0.0f;
-						winv.yx = refined_rcp(wr.dx), winv.yy = refined_rcp(wr.dy), winv.yz = refined_rcp(wr.dz);
-						level = 0, cr = wr, cinv = winv, cnodes = sc.nodes + sc.top_node_base, sp = 0, base = 0, pend = 0u;
+						best_hit = false, best_distance = INFINITY;
+						ledger[L_T] = 0u, ledger[L_PRIM] = 0xFFFFFFFFu, ledger[L_INST] = 0xFFFFFFFFu, ledger[L_U] = 0u, ledger[L_V] = 0u;
+						cinv.yx = refined_rcp(cr.dx), cinv.yy = refined_rcp(cr.dy), cinv.yz = refined_rcp(cr.dz);
+						level = 0, cnode_base = sc.top_node_base, sp = 0, base = 0, pend = 0u;
 						float tn;
-						ref = slab_test<true>(sc.top_min[0], sc.top_min[1], sc.top_min[2], sc.top_max[0], sc.top_max[1], sc.top_max[2], wr, winv, tn) ? sc.top_ref : REF_DONE;
+						ref = slab_test<true>(sc.top_min[0], sc.top_min[1], sc.top_min[2], sc.top_max[0], sc.top_max[1], sc.top_max[2], cr, cinv, tn) ? sc.top_ref : REF_DONE;
 						settle_top();
 					} else {
 						slow_list[atomicAdd(slow_count, 1u)] = out_index;   // finished by the one-ray-per-lane kernel with plain divisions
@@ -197,9 +216,9 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 			prof[1]++, prof[2] += n_walk;
 #endif
 			if (can_walk) {
-				const bool run_hit = level ? mh.hit : best.hit;
-				const float run_dist = level ? mh.distance : best.distance;
-				node_step<MODE, false, true, false>(cnodes, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
+				const bool run_hit = level ? mh.hit : best_hit;
+				const float run_dist = level ? mh.distance : best_distance;
+				node_step<MODE, false, true, false>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
 				if (level == 0u) settle_top();
 			}
 		} else if (n_tri == n_max) {
@@ -208,7 +227,7 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 			prof[3]++, prof[4] += n_tri;
 #endif
 			if (has_parked) {
-				mesh_leaf<MODE, false, false>(ctris, (pend & REF_INDEX_MASK) >> 4, pend & 15u, cr, mh, nullptr);
+				mesh_leaf<MODE, false, false>(sc.tris + ctri_base, (pend & REF_INDEX_MASK) >> 4, pend & 15u, cr, mh, nullptr);
 				pend = 0u;
 			}
 		} else if (n_exit == n_max) {
@@ -218,6 +237,7 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 			prof[5]++, prof[6] += n_exit;
 #endif
 			if (want_exit) {
+				const uint32_t leaf = ledger[L_TOP_LEAF], cur_inst = (leaf & REF_INDEX_MASK) >> 4;
 				const InstRec& in = sc.insts[cur_inst];
 				float dist = mh.distance;
 				if (mh.hit && in.has_transform) {
@@ -227,8 +247,8 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 					mat_point(in.T, cr.ox, cr.oy, cr.oz, qx, qy, qz);
 					dist = norm3(wx - qx, wy - qy, wz - qz);
 				}
-				fold_world(mh.hit, dist, mh.t, mh.prim, mh.u, mh.v);
-				next_top();
+				fold_world(cur_inst, mh.hit, dist, mh.t, mh.prim, mh.u, mh.v);
+				next_top(leaf);
 			}
 		} else {
 			// ---- enter an instance (instance.h:32-35): ray to object space, then the sphere test or the
@@ -237,10 +257,10 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 			prof[7]++, prof[8] += n_enter;
 #endif
 			if (want_enter) {
-				cur_inst = ((top_leaf & REF_INDEX_MASK) >> 4) + inst_k;
+				const uint32_t leaf = ref, cur_inst = (leaf & REF_INDEX_MASK) >> 4;
 				const InstRec& in = sc.insts[cur_inst];
-				Ray3 r = wr;
-				if (in.has_transform) r = ray_transform(in.iT, wr);
+				Ray3 r = cr;
+				if (in.has_transform) r = ray_transform(in.iT, cr);
 				if (in.mesh < 0) {
 					float t;
 					const bool hit = sphere_test(in.radius, r, t);
@@ -252,26 +272,30 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 						mat_point(in.T, r.ox, r.oy, r.oz, qx, qy, qz);
 						dist = norm3(wx - qx, wy - qy, wz - qz);
 					}
-					fold_world(hit, dist, t, 0u, 0.0f, 0.0f);
-					next_top();
+					fold_world(cur_inst, hit, dist, t, 0u, 0.0f, 0.0f);
+					next_top(leaf);
 				} else {
 					const MeshRec& mesh = sc.meshes[in.mesh];
 					if (mesh.is_list || !mesh.tame || !ray_in_fast_range(r)) {
 						// outside what this kernel handles exactly: hand the whole ray to the plain kernel
-						slow_list[atomicAdd(slow_count, 1u)] = out_index;
+						slow_list[atomicAdd(slow_count, 1u)] = ledger[L_OUT];
 						have_ray = false, ref = REF_DONE, pend = 0u, level = 0u;
 					} else {
 						// BVH<Triangle>::hit (bvh.cpp:246-270): running Trace starts at hit = false, distance = inf
 						mh.hit = false, mh.distance = INFINITY, mh.prim = 0xFFFFFFFFu, mh.t = 0.0f, mh.u = mh.v = 0.0f;
-						cr = r;
-						cinv.yx = refined_rcp(r.dx), cinv.yy = refined_rcp(r.dy), cinv.yz = refined_rcp(r.dz);
+						RayInv rinv;
+						rinv.yx = refined_rcp(r.dx), rinv.yy = refined_rcp(r.dy), rinv.yz = refined_rcp(r.dz);
 						float tn;
-						if (slab_test<true>(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], cr, cinv, tn)) {
+						if (slab_test<true>(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], r, rinv, tn)) {
+							lds_world_ray[threadIdx.x] = make_float4(cr.ox, cr.oy, cr.oz, cr.dx);
+							lds_world_ray[256 + threadIdx.x] = make_float4(cr.dy, cr.dz, cr.tmin, cr.tmax);
+							ledger[L_TOP_LEAF] = leaf;
+							cr = r, cinv = rinv;
 							level = 1u, base = sp, ref = mesh.root_ref;
-							cnodes = sc.nodes + mesh.node_base, ctris = sc.tris + mesh.tri_base;
+							cnode_base = mesh.node_base, ctri_base = mesh.tri_base;
 						} else {
-							fold_world(false, 0.0f, 0.0f, 0u, 0.0f, 0.0f);
-							next_top();
+							fold_world(cur_inst, false, 0.0f, 0.0f, 0u, 0.0f, 0.0f);
+							next_top(leaf);
 						}
 					}
 				}
@@ -279,7 +303,11 @@ __global__ void __launch_bounds__(256) k_scene_persistent(SceneRec sc, IO io, un
 		}
 
 		if (have_ray && level == 0u && ref == REF_DONE) {
-			io.store(out_index, best);
+			SceneHit best;
+			best.hit = best_hit, best.distance = best_distance;
+			best.t = __uint_as_float(ledger[L_T]), best.prim = ledger[L_PRIM], best.inst = ledger[L_INST];
+			best.u = __uint_as_float(ledger[L_U]), best.v = __uint_as_float(ledger[L_V]);
+			io.store(ledger[L_OUT], best);
 			have_ray = false;
 		}
 	}
@@ -318,7 +346,7 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 	uint32_t* slow_count = reinterpret_cast<uint32_t*>(counters) + 16;   // same zeroed block, its own 64-byte line
 	PTX_HIP(hipMemsetAsync(counters, 0, 256, s->stream));
 	// Tuning knobs for experiments (not part of the ABI).
-	static const int blocks_per_cu = getenv("PTX_SCENE_BLOCKS_PER_CU") ? atoi(getenv("PTX_SCENE_BLOCKS_PER_CU")) : 4;
+	static const int blocks_per_cu = getenv("PTX_SCENE_BLOCKS_PER_CU") ? atoi(getenv("PTX_SCENE_BLOCKS_PER_CU")) : 5;
 	static const int refill_min = getenv("PTX_SCENE_REFILL_MIN_IDLE") ? atoi(getenv("PTX_SCENE_REFILL_MIN_IDLE")) : SCENE_REFILL_MIN_IDLE;
 	const uint64_t want = (max_items + 255) / 256;
 	const dim3 block(256), grid(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu))))));

@@ -105,20 +105,39 @@ __global__ void __launch_bounds__(256) k_init_slots(const TileRec* __restrict__ 
 	}
 }
 
-// Appends `value` for every lane with `keep` set: one atomic per wave.
-__device__ __forceinline__ void wave_append(bool keep, uint32_t value, uint32_t* list, uint32_t* count) {
+// Appends `value` for every thread with `keep` set, in thread order: one atomic per block.  Every
+// thread of the block calls it.  (One atomic per wave, all on the one counter, was what the ray
+// generation and shading kernels spent most of their time on: same-address atomics retire one at a
+// time, some 13 ns each.)
+template<int WAVES>
+__device__ __forceinline__ void block_append(bool keep, uint32_t value, uint32_t* list, uint32_t* count) {
+	__shared__ uint32_t wave_base[WAVES];
+	const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const unsigned long long mask = __ballot(keep);
-	if (mask == 0ull) return;
-	const unsigned lane = threadIdx.x & 63u;
-	const unsigned leader = __ffsll((long long)mask) - 1;
-	uint32_t base = 0;
-	if (lane == leader) base = atomicAdd(count, uint32_t(__popcll(mask)));
-	base = __shfl(base, leader);
-	if (keep) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+	if (lane == 0) wave_base[wave] = uint32_t(__popcll(mask));
+	__syncthreads();
+	if (threadIdx.x < 64) {   // first wave: exclusive prefix over the waves' counts, one atomic for the block
+		const uint32_t c = lane < WAVES ? wave_base[lane] : 0u;
+		uint32_t incl = c;
+		for (int d = 1; d < WAVES; d <<= 1) {
+			const uint32_t o = __shfl_up(incl, d);
+			if (int(lane) >= d) incl += o;
+		}
+		const uint32_t total = __shfl(incl, WAVES - 1);
+		uint32_t base = 0;
+		if (lane == 0 && total) base = atomicAdd(count, total);
+		base = __shfl(base, 0);
+		if (lane < WAVES) wave_base[lane] = base + incl - c;
+	}
+	__syncthreads();
+	if (keep) list[wave_base[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
+constexpr int RAYGEN_BLOCK = 1024;
+constexpr int shade_block(bool delta) { return delta ? 256 : 1024; }   // the variant walking shadow rays needs 206 VGPRs
+
 // Camera::sample_ray for sample `k` of every slot that has one (pathtracer.cpp:448-454).
-__global__ void __launch_bounds__(256) k_raygen(RenderBuffers rb, uint32_t n_slots, uint32_t k, CameraRec cam, uint32_t key0, uint32_t key1,
+__global__ void __launch_bounds__(RAYGEN_BLOCK) k_raygen(RenderBuffers rb, uint32_t n_slots, uint32_t k, CameraRec cam, uint32_t key0, uint32_t key1,
                                                 uint32_t* __restrict__ out_list, uint32_t* __restrict__ out_count) {
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
 	bool live = false;
@@ -140,7 +159,7 @@ __global__ void __launch_bounds__(256) k_raygen(RenderBuffers rb, uint32_t n_slo
 			store_rec(rb.rays + 2 * slot, PtxRay{{r.ox, r.oy, r.oz}, {r.dx, r.dy, r.dz}, r.tmin, r.tmax});
 		}
 	}
-	wave_append(live, slot, out_list, out_count);
+	block_append<RAYGEN_BLOCK / 64>(live, slot, out_list, out_count);
 }
 
 // Closest hit for the main ray of every active path and for its direct ray when it has one.
@@ -229,8 +248,10 @@ __device__ __forceinline__ Surface rebuild_surface(const SceneRec& sc, const Sha
 }
 
 // The body of Pathtracer::trace for one active path, one recursion level per launch.
-template<int MODE>
-__global__ void __launch_bounds__(256) k_shade(SceneRec sc, ShadeTables sh, RenderBuffers rb, const uint32_t* __restrict__ list,
+// DELTA: the scene has point/spot/directional lights, whose shadow rays are walked in place; scenes
+// without them get an instance of the kernel free of the traversal's registers and stack.
+template<int MODE, bool DELTA>
+__global__ void __launch_bounds__(shade_block(DELTA)) k_shade(SceneRec sc, ShadeTables sh, RenderBuffers rb, const uint32_t* __restrict__ list,
                                                const uint32_t* __restrict__ count, uint32_t key0, uint32_t key1,
                                                uint32_t* __restrict__ next_list, uint32_t* __restrict__ next_count) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -276,7 +297,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneRec sc, ShadeTables sh, Rend
 			if (camera) L = L + emissive;   // an indirect ray contributes `.second` only
 			if (ps.depth != 0 && m.type != PTX_MAT_EMISSIVE) {   // pathtracer.cpp:163
 				// sum_delta_lights (pathtracer.cpp:645-666)
-				if (!mat_is_specular(m.type)) {
+				if (DELTA && !mat_is_specular(m.type)) {
 					for (uint32_t li = 0; li < sh.n_delta_lights; li++) {
 						const IncomingRec inc = light_incoming(sh.delta_lights[li], s.position);
 						const V3f in_dir = f.to_local(inc.direction);
@@ -329,7 +350,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneRec sc, ShadeTables sh, Rend
 			}
 		}
 	}
-	wave_append(alive, slot, next_list, next_count);
+	block_append<shade_block(DELTA) / 64>(alive, slot, next_list, next_count);
 }
 
 // Pathtracer::accumulate (pathtracer.cpp:407-427)
@@ -437,7 +458,7 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		const bool persistent = scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && ns >= (1u << 18);
 		for (uint32_t k = 0; k < max_samples; k++) {
 			PTX_HIP(hipMemsetAsync(rb.counts, 0, 256, s->stream));
-			hipLaunchKernelGGL(k_raygen, grid_slots, block, 0, s->stream, rb, ns, k, cr, key0, key1, rb.active[0], rb.counts + 0);
+			hipLaunchKernelGGL(k_raygen, dim3((ns + RAYGEN_BLOCK - 1) / RAYGEN_BLOCK), dim3(RAYGEN_BLOCK), 0, s->stream, rb, ns, k, cr, key0, key1, rb.active[0], rb.counts + 0);
 			int cur = 0;
 			// A camera ray of depth D has at most D+1 vertices on its main path (depths D..0): the
 			// vertex of depth 0 never scatters, so after D+1 rounds no path is alive and every
@@ -449,7 +470,9 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 					hipLaunchKernelGGL(k_extend<MODE_CULLED>, grid_items, block, 0, s->stream, s->rec, rb, rb.active[cur], rb.counts + cur);
 				}
 				PTX_HIP(hipMemsetAsync(rb.counts + (cur ^ 1), 0, sizeof(uint32_t), s->stream));
-				hipLaunchKernelGGL(k_shade<MODE_CULLED>, grid_slots, block, 0, s->stream, s->rec, s->shade, rb, rb.active[cur], rb.counts + cur, key0, key1,
+				const bool delta = s->shade.n_delta_lights != 0;
+				const auto shade = delta ? k_shade<MODE_CULLED, true> : k_shade<MODE_CULLED, false>;
+				hipLaunchKernelGGL(shade, dim3((ns + shade_block(delta) - 1) / shade_block(delta)), dim3(shade_block(delta)), 0, s->stream, s->rec, s->shade, rb, rb.active[cur], rb.counts + cur, key0, key1,
 				                   rb.active[cur ^ 1], rb.counts + (cur ^ 1));
 				cur ^= 1;
 			}

@@ -441,6 +441,7 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const PtxRay* 
 	static const char* tri_env = getenv("PTX_TRI_MIN_LANES");
 	const int tri_min = tri_env ? atoi(tri_env) : (culled ? PARK_MIN_LANES : TRI_MIN_LANES);
 	static const int stuck_max = getenv("PTX_STUCK_MAX_LANES") ? atoi(getenv("PTX_STUCK_MAX_LANES")) : STUCK_MAX_LANES;
+	static const unsigned long long wave_chunk = getenv("PTX_WAVE_CHUNK") ? std::max(1, atoi(getenv("PTX_WAVE_CHUNK"))) : WAVE_CHUNK;
 	const dim3 block(256), grid(uint32_t(std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu)))));
 	const uint32_t slot = uint32_t(s->timed_launches % PtxScene::TIMING_RING);
 	if (!s->t_start[slot]) {
@@ -448,8 +449,8 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const PtxRay* 
 		PTX_HIP(hipEventCreate(&s->t_stop[slot]));
 	}
 	PTX_HIP(hipEventRecord(s->t_start[slot], s->stream));
-	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max);
-	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max);
+	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
+	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
 	PTX_HIP(hipEventRecord(s->t_stop[slot], s->stream));
 	s->timed_launches++;
 #ifdef PTX_PROFILE_LANES

@@ -69,7 +69,7 @@ struct BatchIO {   // ptx_trace_closest on a general scene
 // version only four fit; the same render took 11 % longer.)
 template<typename IO>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_scene_persistent(SceneRec sc, IO io, unsigned long long* __restrict__ next_item, uint32_t* __restrict__ slow_list,
-                                                          uint32_t* __restrict__ slow_count, const int refill_min) {
+                                                          uint32_t* __restrict__ slow_count, const int refill_min, const unsigned long long wave_chunk) {
 	constexpr int MODE = MODE_CULLED;
 	const unsigned lane = threadIdx.x & 63u;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -158,9 +158,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 		if (!pool_empty && n_dry >= refill_min) {
 			if (chunk_next >= chunk_end) {
 				unsigned long long b = 0;
-				if (lane == 0) b = atomicAdd(next_item, SCENE_WAVE_CHUNK);
+				if (lane == 0) b = atomicAdd(next_item, wave_chunk);
 				b = __shfl(b, 0);
-				chunk_next = b, chunk_end = b + SCENE_WAVE_CHUNK < n_items ? b + SCENE_WAVE_CHUNK : n_items;
+				chunk_next = b, chunk_end = b + wave_chunk < n_items ? b + wave_chunk : n_items;
 				if (b >= n_items) chunk_next = chunk_end = n_items;
 			}
 			const unsigned long long b = chunk_next;
@@ -348,9 +348,10 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 	// Tuning knobs for experiments (not part of the ABI).
 	static const int blocks_per_cu = getenv("PTX_SCENE_BLOCKS_PER_CU") ? atoi(getenv("PTX_SCENE_BLOCKS_PER_CU")) : 5;
 	static const int refill_min = getenv("PTX_SCENE_REFILL_MIN_IDLE") ? atoi(getenv("PTX_SCENE_REFILL_MIN_IDLE")) : SCENE_REFILL_MIN_IDLE;
+	static const unsigned long long wave_chunk = getenv("PTX_SCENE_WAVE_CHUNK") ? std::max(1, atoi(getenv("PTX_SCENE_WAVE_CHUNK"))) : SCENE_WAVE_CHUNK;
 	const uint64_t want = (max_items + 255) / 256;
 	const dim3 block(256), grid(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu))))));
-	hipLaunchKernelGGL((k_scene_persistent<IO>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count, refill_min);
+	hipLaunchKernelGGL((k_scene_persistent<IO>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count, refill_min, wave_chunk);
 #ifdef PTX_PROFILE_LANES
 	{
 		static unsigned long long tot[9] = {};

@@ -372,7 +372,7 @@ int scene_scratch(PtxScene* s, int slot, size_t bytes) {
 int scene_counter_block(PtxScene* s, unsigned long long** out) {
 	if (!s->next_ray) {
 		void* p = nullptr;
-		PTX_HIP(hipMalloc(&p, 256));
+		PTX_HIP(hipMalloc(&p, COUNTER_BLOCK_BYTES));
 		s->allocations.push_back(p);
 		s->next_ray = static_cast<unsigned long long*>(p);
 	}
@@ -428,7 +428,7 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const PtxRay* 
 		if (int rc = sort_rays(s, d_rays, n, &order)) return rc;
 	unsigned long long* counters = nullptr;
 	if (int rc = scene_counter_block(s, &counters)) return rc;
-	PTX_HIP(hipMemsetAsync(s->next_ray, 0, 256, s->stream));
+	PTX_HIP(hipMemsetAsync(s->next_ray, 0, COUNTER_BLOCK_BYTES, s->stream));
 	if (n >= (uint64_t(1) << 32)) return fail(PTX_ERR_INVALID, "ray count too large for one launch");
 	if (int rc = grow_scratch(s, 7, n * sizeof(uint32_t))) return rc;   // rays deferred to the plain-division kernel
 	uint32_t* slow_list = static_cast<uint32_t*>(s->scratch[7]);

@@ -65,8 +65,9 @@ def cpu_baseline_and_counts(verts, idx, nodes, order, rays, target_seconds=12.0)
     n = int(min(len(rays), max(32768, 32768 * target_seconds / max(dt, 1e-3))))
     n = (n // 4096) * 4096
     t0 = time.perf_counter()
-    run(rays[:n])
+    got = run(rays[:n])
     dt = time.perf_counter() - t0
+    out["sample_hits"] = got["hits"]   # (distance, primitive position in tree order) of the timed sample, for the caller's parity check
     out["cpu_baseline"] = {"value": round(n / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": kind,
                            "sample": f"first {n} rays of the same 16M-ray batch, closest-hit, BVH<Triangle>::hit on the same 1M-triangle tree"}
     out["nodes_per_ray"] = nodes_per_ray
@@ -306,6 +307,13 @@ def main():
         if world == 1 and not args.no_cpu:
             extra = cpu_baseline_and_counts(verts, idx, nodes, order, rays_h)
             result["cpu_baseline"] = extra["cpu_baseline"]
+            # the CPU side's answers on its sample against the GPU's for the same rays: distance bits and primitive
+            cpu_hits = extra["sample_hits"]
+            gpu_hits = hits[:len(cpu_hits)].cpu().numpy()
+            cpu_prim = cpu_hits["prim"].astype(np.uint32).view(np.int32)
+            bad = (cpu_hits["distance"].view(np.int32) != gpu_hits[:, 0]) | (cpu_prim != gpu_hits[:, 1])
+            result["parity"]["cpu_" + extra["cpu_baseline"]["kind"] + "_vs_gpu_mismatches"] = int(bad.sum())
+            result["parity"]["cpu_rays_checked"] = int(len(cpu_hits))
         if extra:
             # algorithmic bytes per ray: ray in + hit out + 32 B per node box tested + 36 B per triangle
             # tested by a reference-semantics traversal of the canonical binary tree

@@ -1,6 +1,7 @@
 // bvh_build.h -- host-side binned-SAH builder: the GPU path's PT::BVH<P>::build.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "../../include/ptx.h"
@@ -14,6 +15,21 @@ struct HostBvh {
 	uint64_t predicate_disagreements = 0;
 	uint64_t dropped = 0;            // primitives under nodes no split separates
 	uint32_t max_depth = 0;          // root = depth 0
+};
+
+// Worker threads the host-side passes over large inputs use: the CPUs this process may run on, at most
+// 16 (the environment variable PTX_BUILD_THREADS overrides).
+unsigned build_threads();
+
+// fn(begin, end) over [0, n) cut into one slice per thread; runs inline when n is small.
+void parallel_slices(uint64_t n, const std::function<void(uint64_t, uint64_t)>& fn);
+
+// Lap timer for the scene-construction passes, printing to stderr when PTX_BUILD_PROFILE is set.
+struct BuildLaps {
+	BuildLaps();
+	void lap(const char* what);
+	bool on;
+	double last;
 };
 
 // Triangle::bbox (tri_mesh.cpp:10-44) for every triangle of an indexed mesh with 8-float vertices.

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -237,8 +238,13 @@ template<typename T> static int upload(PtxScene* s, const std::vector<T>& v, con
 
 static int check_mesh_desc(const PtxMeshDesc& m) {
 	if (m.n_tris && (!m.verts || !m.indices)) return fail(PTX_ERR_INVALID, "mesh with triangles but null verts/indices");
-	for (uint64_t i = 0; i < uint64_t(m.n_tris) * 3; i++)
-		if (m.indices[i] >= m.n_verts) return fail(PTX_ERR_INVALID, "triangle index out of range");
+	std::atomic<bool> bad_index{false};
+	parallel_slices(uint64_t(m.n_tris) * 3, [&](uint64_t lo, uint64_t hi) {
+		bool bad = false;
+		for (uint64_t i = lo; i < hi; i++) bad |= m.indices[i] >= m.n_verts;
+		if (bad) bad_index = true;
+	});
+	if (bad_index) return fail(PTX_ERR_INVALID, "triangle index out of range");
 	const uint32_t max_leaf = m.max_leaf_size ? m.max_leaf_size : 4;
 	if (m.use_bvh && !m.nodes && max_leaf > MAX_LEAF_PRIMS) return fail(PTX_ERR_UNSUPPORTED, "max_leaf_size above 15 is not representable in the GPU layout");
 	return PTX_OK;
@@ -262,7 +268,9 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 	rec.is_list = m.use_bvh ? 0 : 1;
 	HostBvh bvh;
 	std::vector<float> boxes;
+	BuildLaps laps;
 	triangle_boxes(m.verts, m.indices, m.n_tris, boxes);
+	laps.lap("mesh: triangle boxes");
 	float mesh_box[6];
 	if (m.nodes) {
 		if (!m.n_nodes) return fail(PTX_ERR_INVALID, "injected tree with zero nodes");
@@ -275,11 +283,15 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 		bvh.order.resize(m.n_tris);
 		for (uint32_t i = 0; i < m.n_tris; i++) bvh.order[i] = i;
 	}
+	laps.lap("mesh: tree");
 	if (!rec.is_list) {
 		FlatTree ft;
 		std::vector<float> ordered(boxes.size());
-		for (uint32_t i = 0; i < m.n_tris; i++) std::copy(&boxes[size_t(bvh.order[i]) * 6], &boxes[size_t(bvh.order[i]) * 6] + 6, &ordered[size_t(i) * 6]);
+		parallel_slices(m.n_tris, [&](uint64_t lo, uint64_t hi) {
+			for (uint64_t i = lo; i < hi; i++) std::copy(&boxes[size_t(bvh.order[i]) * 6], &boxes[size_t(bvh.order[i]) * 6] + 6, &ordered[size_t(i) * 6]);
+		});
 		if (int rc = flatten_tree(bvh.nodes.data(), uint32_t(bvh.nodes.size()), m.n_tris, ordered.data(), ft)) return rc;
+		laps.lap("mesh: GPU node layout");
 		bvh.max_depth = ft.depth;
 		rec.root_ref = ft.root_ref;
 		rec.tame = ft.tame ? 1 : 0;
@@ -297,8 +309,12 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 			}
 	}
 	sb.mesh_box.emplace_back(mesh_box, mesh_box + 6);
-	for (uint32_t i = 0; i < m.n_tris; i++) {
-		const uint32_t t = bvh.order[i];
+	const size_t tri0 = sb.tris.size();
+	sb.tris.resize(tri0 + m.n_tris);
+	sb.attrs.resize(tri0 + m.n_tris);
+	parallel_slices(m.n_tris, [&](uint64_t lo, uint64_t hi) {
+	for (uint64_t i = lo; i < hi; i++) {
+		const size_t t = bvh.order[i];
 		const float* a = m.verts + size_t(m.indices[t * 3 + 0]) * 8;
 		const float* b = m.verts + size_t(m.indices[t * 3 + 1]) * 8;
 		const float* c = m.verts + size_t(m.indices[t * 3 + 2]) * 8;
@@ -311,15 +327,18 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 			at.n0[k] = a[3 + k], at.n1[k] = b[3 + k], at.n2[k] = c[3 + k];
 		}
 		for (int k = 0; k < 2; k++) at.uv0[k] = a[6 + k], at.uv1[k] = b[6 + k], at.uv2[k] = c[6 + k];
-		sb.tris.push_back(g);
-		sb.attrs.push_back(at);
+		sb.tris[tri0 + i] = g;
+		sb.attrs[tri0 + i] = at;
 	}
+	});
+	laps.lap("mesh: triangle records");
 	sb.meshes.push_back(rec);
 	s->mesh_bvhs.push_back(std::move(bvh));
 	return PTX_OK;
 }
 
 static int finish_geometry(PtxScene* s, SceneBuild& sb) {
+	BuildLaps laps;
 	if (int rc = upload(s, sb.nodes, s->rec.nodes)) return rc;
 	if (int rc = upload(s, sb.tris, s->rec.tris)) return rc;
 	if (int rc = upload(s, sb.attrs, s->rec.attrs)) return rc;
@@ -327,6 +346,7 @@ static int finish_geometry(PtxScene* s, SceneBuild& sb) {
 	s->shade.attrs = s->rec.attrs;
 	s->bytes_nodes = sb.nodes.size() * sizeof(Node2);
 	s->bytes_tris = sb.tris.size() * sizeof(TriGeom);
+	laps.lap("upload");
 	return PTX_OK;
 }
 

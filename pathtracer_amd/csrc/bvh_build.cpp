@@ -226,13 +226,6 @@ void bin_range(const BuildInput& in, const PtxBvhNode& parent, uint32_t begin, u
 void split_node(const BuildInput& in, const PtxBvhNode& parent, Workers* workers, PtxBvhNode& left, PtxBvhNode& right, Counters& c) {
 	const unsigned threads = workers ? workers->size() : 1u;
 	const uint32_t begin = parent.start, count = parent.size;
-	const bool prof = std::getenv("PTX_BUILD_PROFILE2") && count > 1000000;
-	auto t_last = std::chrono::steady_clock::now();
-	auto lap = [&](const char* what) {
-		const auto now = std::chrono::steady_clock::now();
-		if (prof) std::fprintf(stderr, "   [split %u] %-20s %.4f s\n", count, what, std::chrono::duration<double>(now - t_last).count());
-		t_last = now;
-	};
 	Bins bins;
 	if (threads > 1 && count >= (1u << 16)) {
 		std::vector<Bins> part(threads);
@@ -245,7 +238,6 @@ void split_node(const BuildInput& in, const PtxBvhNode& parent, Workers* workers
 		bin_range(in, parent, begin, begin + count, bins);
 	}
 	c.clamped += bins.clamped;
-	lap("bins");
 
 	float best_cost = INFINITY;
 	int best_axis = 0, best_plane = 0;
@@ -298,7 +290,6 @@ void split_node(const BuildInput& in, const PtxBvhNode& parent, Workers* workers
 		});
 		uint32_t n_left = 0;
 		for (unsigned k = 1; k <= threads; k++) n_left += slice_n[k];
-		lap("flags");
 		// misplaced elements of the front part (flag 0) and of the back part (flag 1), positions ascending
 		std::vector<uint32_t> f_n(threads + 1, 0u), b_n(threads + 1, 0u);
 		workers->run(threads, [&](unsigned k) {
@@ -310,7 +301,6 @@ void split_node(const BuildInput& in, const PtxBvhNode& parent, Workers* workers
 			b_n[k + 1] = c;
 		});
 		for (unsigned k = 1; k <= threads; k++) f_n[k] += f_n[k - 1], b_n[k] += b_n[k - 1];
-		lap("counts");
 		const uint32_t m = f_n[threads];   // == b_n[threads]
 		std::vector<uint32_t> f_pos(m), b_pos(m);
 		workers->run(threads, [&](unsigned k) {
@@ -324,7 +314,6 @@ void split_node(const BuildInput& in, const PtxBvhNode& parent, Workers* workers
 		workers->run(threads, [&](unsigned k) {
 			for (uint32_t i = slice(0, m, k); i < slice(0, m, k + 1); i++) std::swap(order[f_pos[i]], order[b_pos[m - 1 - i]]);
 		});
-		lap("positions + swaps");
 		front = begin + n_left;
 	} else {
 		for (;;) {
@@ -422,7 +411,7 @@ void build_bvh(const float* boxes, uint32_t n, uint32_t max_leaf_size, HostBvh& 
 		};
 		std::vector<Top> top(1);
 		top[0].node = root;
-		const uint32_t hand_out = std::max<uint32_t>(4096u, n / (threads * (std::getenv("PTX_BUILD_SPLIT") ? unsigned(std::atoi(std::getenv("PTX_BUILD_SPLIT"))) : 8u)));
+		const uint32_t hand_out = std::max<uint32_t>(4096u, n / (threads * 8u));
 		std::vector<uint32_t> tasks;
 		std::vector<uint32_t> pending{0u};
 		while (!pending.empty()) {

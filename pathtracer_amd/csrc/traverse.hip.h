@@ -193,8 +193,13 @@ struct Stack {
 
 template<int LDS_SLOTS, int STRIDE>
 struct LdsStack {
-	uint32_t* lds_ref;    // &lds_ref_array[threadIdx.x]
-	float* lds_tnear;
+	// LDS pointers carry their address space in the type: through a generic pointer the reads below
+	// become flat loads, which go through the vector-memory path even though they land in LDS.
+	typedef __attribute__((address_space(3))) uint32_t LdsU32;
+	typedef __attribute__((address_space(3))) float LdsF32;
+	LdsU32* lds_ref;    // &lds_ref_array[threadIdx.x]
+	LdsF32* lds_tnear;
+	__device__ __forceinline__ LdsStack(uint32_t* ref, float* tnear, Stack* sp) : lds_ref((LdsU32*)ref), lds_tnear((LdsF32*)tnear), spill(sp) {}
 	Stack* spill;
 	__device__ __forceinline__ void push(int sp, uint32_t r, float t) {
 		if (sp < LDS_SLOTS) lds_ref[sp * STRIDE] = r, lds_tnear[sp * STRIDE] = t;
@@ -204,8 +209,19 @@ struct LdsStack {
 		if (sp < LDS_SLOTS) lds_ref[sp * STRIDE] = r;
 		else spill->push(sp - LDS_SLOTS, r);
 	}
-	__device__ __forceinline__ uint32_t get_ref(int sp) const { return sp < LDS_SLOTS ? lds_ref[sp * STRIDE] : spill->get_ref(sp - LDS_SLOTS); }
-	__device__ __forceinline__ float get_tnear(int sp) const { return sp < LDS_SLOTS ? lds_tnear[sp * STRIDE] : spill->get_tnear(sp - LDS_SLOTS); }
+	// The LDS entry is read whatever sp is (clamped, through a volatile pointer) and replaced under a
+	// branch when the entry lives in scratch: left free, the compiler picks between the two ADDRESSES and
+	// issues one flat load.
+	__device__ __forceinline__ uint32_t get_ref(int sp) const {
+		uint32_t v = *(const volatile LdsU32*)(lds_ref + (sp < LDS_SLOTS ? sp : LDS_SLOTS - 1) * STRIDE);
+		if (__builtin_expect(sp >= LDS_SLOTS, 0)) v = spill->get_ref(sp - LDS_SLOTS);
+		return v;
+	}
+	__device__ __forceinline__ float get_tnear(int sp) const {
+		float v = *(const volatile LdsF32*)(lds_tnear + (sp < LDS_SLOTS ? sp : LDS_SLOTS - 1) * STRIDE);
+		if (__builtin_expect(sp >= LDS_SLOTS, 0)) v = spill->get_tnear(sp - LDS_SLOTS);
+		return v;
+	}
 };
 
 // ---- traversal steps ------------------------------------------------------------------------

@@ -52,6 +52,9 @@ enum {
 	 *   reference resolves them (largest position in the BVH-ordered primitive array wins,
 	 *   trace.h:28-36).  Same answers as REFERENCE on well-conditioned input; verified, not
 	 *   proven (a near-parallel ray/triangle pair can compute a distance far from the true one).
+	 *   A ray with a NaN or infinite component, or whose hit distance comes out NaN, is walked in
+	 *   the reference order whatever this flag says: with NaN distances Trace::min's winner is a
+	 *   matter of test order.
 	 */
 	PTX_TRAVERSE_REFERENCE = 0u << 4,
 	PTX_TRAVERSE_CULLED = 1u << 4,

@@ -248,6 +248,7 @@ __global__ void __launch_bounds__(256) k_mesh_deferred(SceneRec sc, const PtxRay
 		Stack st;
 		MeshHit cur;
 		traverse_mesh<MODE, ANY, false>(sc, sc.meshes[0], r, st, 0, cur, nullptr);
+		if (MODE == MODE_CULLED && !ANY && needs_reference_order(r, cur.hit, cur.distance)) traverse_mesh<MODE_REFERENCE, ANY, false>(sc, sc.meshes[0], r, st, 0, cur, nullptr);
 		if (ANY) {
 			occluded[i] = cur.hit ? 1 : 0;
 		} else {

@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(256) k_trace_closest(SceneRec sc, const PtxRay
 	Stack st;
 	SceneHit h;
 	traverse_scene<MODE, false, false, MESH_ONLY>(sc, r, st, h);
+	if (MODE == MODE_CULLED && needs_reference_order(r, h.hit, h.distance)) traverse_scene<MODE_REFERENCE, false, false, MESH_ONLY>(sc, r, st, h);
 	PtxHit out;
 	out.distance = h.distance;
 	out.prim = h.hit ? h.prim : PTX_NO_HIT;

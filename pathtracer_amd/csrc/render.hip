@@ -175,6 +175,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneRec sc, RenderBuffers rb, c
 	Stack st;
 	SceneHit h;
 	traverse_scene<MODE, false>(sc, r, st, h);
+	if (MODE == MODE_CULLED && needs_reference_order(r, h.hit, h.distance)) traverse_scene<MODE_REFERENCE, false>(sc, r, st, h);
 	HitRec out{};
 	out.distance = h.distance, out.t = h.t, out.u = h.u, out.v = h.v;
 	out.prim = h.hit ? h.prim : 0xFFFFFFFFu, out.inst = h.inst;

@@ -328,6 +328,7 @@ __global__ void __launch_bounds__(256) k_scene_deferred(SceneRec sc, IO io, cons
 		Stack st;
 		SceneHit h;
 		traverse_scene<MODE_CULLED, false>(sc, r, st, h);
+		if (needs_reference_order(r, h.hit, h.distance)) traverse_scene<MODE_REFERENCE, false>(sc, r, st, h);
 		io.store(out, h);
 	}
 }

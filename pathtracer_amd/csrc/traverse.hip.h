@@ -490,6 +490,17 @@ __device__ __forceinline__ bool instance_hit(const SceneRec& sc, uint32_t inst_i
 	return true;
 }
 
+// Where the culled order cannot stand in for the reference's: Trace::min keeps its left argument only
+// when `l.distance < r.distance` (trace.h:28-36), so once a distance is NaN the winner is whichever hit
+// was folded in last -- a matter of test order, which only the reference order reproduces.  NaN
+// distances come from rays with a NaN or infinite component (or a direction too short to normalise,
+// in an instance); such rays are rare and are walked again in the reference order.
+__device__ __forceinline__ bool ray_is_finite(const Ray3& r) {
+	const float s = (r.ox + r.oy + r.oz) + (r.dx + r.dy + r.dz);   // NaN or inf anywhere makes the sum NaN or inf (inf - inf: NaN)
+	return fabsf(s) <= 3.402823466e+38f && r.tmin == r.tmin && r.tmax == r.tmax;
+}
+__device__ __forceinline__ bool needs_reference_order(const Ray3& r, bool hit, float distance) { return !ray_is_finite(r) || (hit && distance != distance); }
+
 // Aggregate::hit over BVH<Instance> / List<Instance> (aggregate.h:41-43), or Tri_Mesh::hit
 // when the scene is a single mesh.
 // MESH_ONLY is a compile-time promise that sc.mesh_only is set: the two-level code is then

@@ -31,6 +31,7 @@ namespace ptx {
 
 constexpr int SCENE_LDS_SLOTS = 8;
 constexpr unsigned long long SCENE_WAVE_CHUNK = 128;
+constexpr int SCENE_WALK_STEPS = 6;   // box steps per WALK phase
 constexpr int SCENE_REFILL_MIN_IDLE = 8;
 constexpr uint32_t SCENE_ITERATION_CAP = 1u << 24;   // per wave; ordinary launches stay below 2^20
 
@@ -69,7 +70,7 @@ struct BatchIO {   // ptx_trace_closest on a general scene
 // version only four fit; the same render took 11 % longer.)
 template<typename IO>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_scene_persistent(SceneRec sc, IO io, unsigned long long* __restrict__ next_item, uint32_t* __restrict__ slow_list,
-                                                          uint32_t* __restrict__ slow_count, const int refill_min, const unsigned long long wave_chunk) {
+                                                          uint32_t* __restrict__ slow_count, const int refill_min, const unsigned long long wave_chunk, const int walk_steps) {
 	constexpr int MODE = MODE_CULLED;
 	const unsigned lane = threadIdx.x & 63u;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -215,11 +216,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 #ifdef PTX_PROFILE_LANES
 			prof[1]++, prof[2] += n_walk;
 #endif
-			if (can_walk) {
-				const bool run_hit = level ? mh.hit : best_hit;
-				const float run_dist = level ? mh.distance : best_distance;
-				node_step<MODE, false, true, false>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
-				if (level == 0u) settle_top();
+			// Several steps in a row: choosing a phase costs about a third of a box step, and a wave that
+			// walks now mostly walks next time too.  Lanes that reach a leaf on the way sit out the rest.
+			// (Measured on two scenes: 6 steps -9 % and -17 % time against 1; parking leaves between the
+			// steps or leaving early when half the walkers are done both lose to the plain loop.)
+			for (int step = 0; step < walk_steps; step++) {
+				if (have_ray && !(ref & REF_LEAF)) {
+					const bool run_hit = level ? mh.hit : best_hit;
+					const float run_dist = level ? mh.distance : best_distance;
+					node_step<MODE, false, true, false>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
+					if (level == 0u) settle_top();
+				}
 			}
 		} else if (n_tri == n_max) {
 			// ---- triangle phase: every parked leaf
@@ -350,9 +357,10 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 	static const int blocks_per_cu = getenv("PTX_SCENE_BLOCKS_PER_CU") ? atoi(getenv("PTX_SCENE_BLOCKS_PER_CU")) : 5;
 	static const int refill_min = getenv("PTX_SCENE_REFILL_MIN_IDLE") ? atoi(getenv("PTX_SCENE_REFILL_MIN_IDLE")) : SCENE_REFILL_MIN_IDLE;
 	static const unsigned long long wave_chunk = getenv("PTX_SCENE_WAVE_CHUNK") ? std::max(1, atoi(getenv("PTX_SCENE_WAVE_CHUNK"))) : SCENE_WAVE_CHUNK;
+	static const int walk_steps = getenv("PTX_SCENE_WALK_STEPS") ? std::max(1, atoi(getenv("PTX_SCENE_WALK_STEPS"))) : SCENE_WALK_STEPS;
 	const uint64_t want = (max_items + 255) / 256;
 	const dim3 block(256), grid(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu))))));
-	hipLaunchKernelGGL((k_scene_persistent<IO>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count, refill_min, wave_chunk);
+	hipLaunchKernelGGL((k_scene_persistent<IO>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count, refill_min, wave_chunk, walk_steps);
 #ifdef PTX_PROFILE_LANES
 	{
 		static unsigned long long tot[9] = {};

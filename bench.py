@@ -104,8 +104,36 @@ def instanced_cow_scene(n):
     return sb, cam
 
 
-def render_leg(name, w, h, spp, depth, rank, world, dev, dist):
-    """One render of a committed reference scene; returns (paths, wall seconds incl. the frame reduce, mean radiance)."""
+def cpu_render_baseline(sb, cam, w, h, spp, target_seconds=4.0):
+    """The CPU checker's Pathtracer::render on a bounded slice of the same render: the first tiles of the reference's
+    centre-out order at a reduced sample count (the reference's cost is linear in samples and pixels), per-tile
+    mt19937 streams as in the reference, one tile per host thread."""
+    from _oracle import Oracle
+    from pathtracer_amd import capi
+    threads = cpu_threads()
+    scene = Oracle().scene(sb.desc())
+    slice_spp = min(spp, 8)
+    cam.film_samples = slice_spp
+    tiles = capi.make_tiles(w, h, slice_spp, 4660)
+    first = tiles[:min(len(tiles), threads)]
+    t0 = time.perf_counter()
+    scene.render_tiles(cam, first, 0, 0, nthreads=threads)
+    dt = time.perf_counter() - t0
+    n_tiles = min(len(tiles), threads * int(max(1, min(16, round(target_seconds / max(dt, 1e-3))))))
+    used = tiles[:n_tiles]
+    t0 = time.perf_counter()
+    scene.render_tiles(cam, used, 0, 0, nthreads=threads)
+    dt = time.perf_counter() - t0
+    cam.film_samples = spp
+    paths = int(((used["x_end"].astype(np.int64) - used["x_begin"]) * (used["y_end"].astype(np.int64) - used["y_begin"]) * (used["s_end"].astype(np.int64) - used["s_begin"])).sum())
+    scene.close()
+    return {"value": round(paths / dt / 1e6, 4), "unit": "Mspp/s", "cores": threads, "kind": "port",
+            "sample": f"first {n_tiles} of {len(tiles)} tiles in the reference's centre-out order at {slice_spp} spp ({paths} paths)"}
+
+
+def render_leg(name, w, h, spp, depth, rank, world, dev, dist, cpu=False):
+    """One render of a committed reference scene; returns (paths, wall seconds incl. the frame reduce, mean radiance,
+    CPU baseline of the same render or None)."""
     import torch
     from pathtracer_amd import abi, capi, dist as pdist
     if name == "instanced_cows":
@@ -136,7 +164,7 @@ def render_leg(name, w, h, spp, depth, rank, world, dev, dist):
     assert int(smp.min().item()) == spp and int(smp.max().item()) == spp
     mean = float((acc.double().sum() / (1 << 24) / (3.0 * w * h * spp)).item())
     scene.close()
-    return w * h * spp, wall, mean
+    return w * h * spp, wall, mean, (cpu_render_baseline(sb, cam, w, h, spp) if cpu else None)
 
 
 def main():
@@ -293,9 +321,12 @@ def main():
             legs.append(("refract_cow_cbox", 3840, 2160, 1024, 8, "config 4: refract_cow_cbox.js3d 3840x2160, 1024 spp, depth 8, tiles dealt across the GPUs"))
         for name, w, h, spp, depth, label in legs:
             note(f"render leg {name} {w}x{h} {spp} spp")
-            paths, rwall, mean = render_leg(name, w, h, spp, depth, rank, world, dev, dist)
+            want_cpu = rank == 0 and world == 1 and not args.no_cpu and not label.startswith("config 4")   # config 4 is config 2's scene
+            paths, rwall, mean, cpu = render_leg(name, w, h, spp, depth, rank, world, dev, dist, cpu=want_cpu)
             renders.append({"workload": label, "paths": paths, "wall_s": round(rwall, 4), "Mspp_per_s": round(paths / rwall / 1e6, 2),
                             "mean_radiance": round(mean, 5), "frame_reduce": (("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) + " all_reduce int64+int32") if world > 1 else "none"})
+            if cpu:
+                renders[-1]["cpu_baseline"] = cpu
     result["renders"] = renders
     if len(renders) >= 2:
         result["render_Mspp_per_s"] = renders[1]["Mspp_per_s"]     # config 2, the one-GPU render configuration

@@ -39,13 +39,15 @@ namespace ptx {
 
 constexpr float RAY_MINIMUM_BOUND = 0.001f;   // pathtracer.cpp:17
 constexpr uint32_t FLAG_CAMERA = 1u, FLAG_HAS_DIRECT = 2u;
-constexpr uint64_t MAX_SLOTS_PER_CHUNK = 8u << 20;
+// Paths in flight per pass (216 B of state each: 14 GB at the limit).  Measured on a 268 M-path render:
+// 8 M paths per pass 0.67 s, 32 M 0.60 s, 128 M 0.59 s.
+constexpr uint64_t MAX_SLOTS_PER_CHUNK = 64u << 20;
 
 struct alignas(16) SlotInfo {
 	uint32_t pixel, s_begin, s_count, pad;
 };
 
-struct alignas(16) PathState {            // 64 bytes per slot
+struct alignas(16) PathState {            // 64 bytes per path
 	float T[3];               // throughput of the main ray's path so far
 	uint32_t depth;           // Ray::depth of the main ray
 	float L[3];               // radiance gathered so far
@@ -59,14 +61,19 @@ struct TileRec {
 	uint32_t x_begin, y_begin, w, h, s_begin, s_count, slot_base, pad;
 };
 
+// A slot is one pixel of one tile; a path is one sample of a slot.  `group` samples of every slot are in
+// flight together: path g * n_slots + slot carries the g-th sample of the current pass of `slot`
+// (neighbouring paths are neighbouring pixels).  Small films thus still fill the chip.
 struct RenderBuffers {
 	SlotInfo* slots;
 	float4* sums;         // per slot: float sum of its samples so far (rgb)
+	float4* rad;          // per path: the radiance its sample ended with
 	PathState* paths;
-	PtxRay* rays;         // 2 per slot: main, direct
-	HitRec* hits;         // 2 per slot
+	PtxRay* rays;         // 2 per path: main, direct
+	HitRec* hits;         // 2 per path
 	uint32_t* active[2];
 	uint32_t* counts;     // [0], [1]: sizes of active[0], active[1]
+	uint32_t n_slots, group;
 };
 
 // Records move between registers and memory as whole 16-byte pieces (one vector load or store per
@@ -136,13 +143,14 @@ __device__ __forceinline__ void block_append(bool keep, uint32_t value, uint32_t
 constexpr int RAYGEN_BLOCK = 1024;
 constexpr int shade_block(bool delta) { return delta ? 256 : 1024; }   // the variant walking shadow rays needs 206 VGPRs
 
-// Camera::sample_ray for sample `k` of every slot that has one (pathtracer.cpp:448-454).
-__global__ void __launch_bounds__(RAYGEN_BLOCK) k_raygen(RenderBuffers rb, uint32_t n_slots, uint32_t k, CameraRec cam, uint32_t key0, uint32_t key1,
+// Camera::sample_ray for samples k0 .. k0 + group - 1 of every slot that has them (pathtracer.cpp:448-454).
+__global__ void __launch_bounds__(RAYGEN_BLOCK) k_raygen(RenderBuffers rb, uint32_t k0, CameraRec cam, uint32_t key0, uint32_t key1,
                                                 uint32_t* __restrict__ out_list, uint32_t* __restrict__ out_count) {
-	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t path = blockIdx.x * blockDim.x + threadIdx.x;
 	bool live = false;
-	if (slot < n_slots) {
-		const SlotInfo si = load_rec(rb.slots + slot);
+	if (path < rb.n_slots * rb.group) {
+		const uint32_t k = k0 + path / rb.n_slots;
+		const SlotInfo si = load_rec(rb.slots + path % rb.n_slots);
 		if (k < si.s_count) {
 			live = true;
 			PathRng rng;
@@ -155,11 +163,11 @@ __global__ void __launch_bounds__(RAYGEN_BLOCK) k_raygen(RenderBuffers rb, uint3
 			ps.draws = rng.draws;
 			ps.flags = FLAG_CAMERA;
 			ps.sample = si.s_begin + k;
-			store_rec(rb.paths + slot, ps);
-			store_rec(rb.rays + 2 * slot, PtxRay{{r.ox, r.oy, r.oz}, {r.dx, r.dy, r.dz}, r.tmin, r.tmax});
+			store_rec(rb.paths + path, ps);
+			store_rec(rb.rays + 2 * path, PtxRay{{r.ox, r.oy, r.oz}, {r.dx, r.dy, r.dz}, r.tmin, r.tmax});
 		}
 	}
-	block_append<RAYGEN_BLOCK / 64>(live, slot, out_list, out_count);
+	block_append<RAYGEN_BLOCK / 64>(live, path, out_list, out_count);
 }
 
 // Closest hit for the main ray of every active path and for its direct ray when it has one.
@@ -313,7 +321,7 @@ __global__ void __launch_bounds__(shade_block(DELTA)) k_shade(SceneRec sc, Shade
 					}
 				}
 				PathRng rng;
-				rng.start(key0, key1, rb.slots[slot].pixel, ps.sample, ps.draws);
+				rng.start(key0, key1, rb.slots[slot % rb.n_slots].pixel, ps.sample, ps.draws);
 				// sample_direct_lighting_task4 (pathtracer.cpp:34-78): weight = attenuation [/ pdf]
 				{
 					const ScatterRec sc1 = bsdf_scatter(sh, m, rng, out_dir, s.u, s.v);
@@ -343,15 +351,25 @@ __global__ void __launch_bounds__(shade_block(DELTA)) k_shade(SceneRec sc, Shade
 			ps.T[0] = T.x, ps.T[1] = T.y, ps.T[2] = T.z, ps.L[0] = L.x, ps.L[1] = L.y, ps.L[2] = L.z;
 			store_rec(rb.paths + slot, ps);
 		} else {
-			// `if (p.valid()) sample.at(px, py) += p;` (pathtracer.cpp:466-470); pdf of the camera sample is 1
-			if (finite3(L)) {
-				float4 sum = rb.sums[slot];
-				sum.x += L.x, sum.y += L.y, sum.z += L.z;
-				rb.sums[slot] = sum;
-			}
+			rb.rad[slot] = make_float4(L.x, L.y, L.z, 0.0f);   // folded into the slot's sum in sample order by k_sum_pass
 		}
 	}
 	block_append<shade_block(DELTA) / 64>(alive, slot, next_list, next_count);
+}
+
+// The samples of one pass added to their slot's sum in sample order, so that the float sum per pixel is
+// the reference's sequence of additions: `if (p.valid()) sample.at(px, py) += p;` (pathtracer.cpp:466-470;
+// the pdf of the camera sample is 1).
+__global__ void __launch_bounds__(256) k_sum_pass(RenderBuffers rb, uint32_t k0) {
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= rb.n_slots) return;
+	const uint32_t s_count = rb.slots[slot].s_count;
+	float4 sum = rb.sums[slot];
+	for (uint32_t g = 0; g < rb.group && k0 + g < s_count; g++) {
+		const float4 L = rb.rad[size_t(g) * rb.n_slots + slot];
+		if (finite3(v3(L.x, L.y, L.z))) sum.x += L.x, sum.y += L.y, sum.z += L.z;
+	}
+	rb.sums[slot] = sum;
 }
 
 // Pathtracer::accumulate (pathtracer.cpp:407-427)
@@ -434,49 +452,56 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		}
 		if (chunk.empty()) continue;
 		const uint32_t ns = uint32_t(n_slots);
+		// samples of a slot in flight together: as many as keep the paths within the state buffers' budget
+		const uint32_t group = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(max_samples, MAX_SLOTS_PER_CHUNK / n_slots)));
+		const uint64_t n_paths = n_slots * group;
 		RenderBuffers rb{};
+		rb.n_slots = ns, rb.group = group;
 		void* p = nullptr;
 		if (int rc = device_alloc(s, 2, chunk.size() * sizeof(TileRec), &p)) return rc;
 		TileRec* d_tiles = static_cast<TileRec*>(p);
-		// one allocation for all per-slot state
-		const size_t bytes = n_slots * (sizeof(SlotInfo) + sizeof(float4) + sizeof(PathState) + 2 * sizeof(PtxRay) + 2 * sizeof(HitRec) + 2 * sizeof(uint32_t)) + 256;
+		// one allocation for all per-slot and per-path state
+		const size_t bytes = n_slots * (sizeof(SlotInfo) + sizeof(float4)) + n_paths * (sizeof(float4) + sizeof(PathState) + 2 * sizeof(PtxRay) + 2 * sizeof(HitRec) + 2 * sizeof(uint32_t)) + 256;
 		if (int rc = device_alloc(s, 3, bytes, &p)) return rc;
 		char* base = static_cast<char*>(p);
 		rb.counts = reinterpret_cast<uint32_t*>(base), base += 256;
-		rb.hits = reinterpret_cast<HitRec*>(base), base += n_slots * 2 * sizeof(HitRec);
-		rb.rays = reinterpret_cast<PtxRay*>(base), base += n_slots * 2 * sizeof(PtxRay);
-		rb.paths = reinterpret_cast<PathState*>(base), base += n_slots * sizeof(PathState);
+		rb.hits = reinterpret_cast<HitRec*>(base), base += n_paths * 2 * sizeof(HitRec);
+		rb.rays = reinterpret_cast<PtxRay*>(base), base += n_paths * 2 * sizeof(PtxRay);
+		rb.paths = reinterpret_cast<PathState*>(base), base += n_paths * sizeof(PathState);
+		rb.rad = reinterpret_cast<float4*>(base), base += n_paths * sizeof(float4);
 		rb.sums = reinterpret_cast<float4*>(base), base += n_slots * sizeof(float4);
 		rb.slots = reinterpret_cast<SlotInfo*>(base), base += n_slots * sizeof(SlotInfo);
-		rb.active[0] = reinterpret_cast<uint32_t*>(base), base += n_slots * sizeof(uint32_t);
+		rb.active[0] = reinterpret_cast<uint32_t*>(base), base += n_paths * sizeof(uint32_t);
 		rb.active[1] = reinterpret_cast<uint32_t*>(base);
 		PTX_HIP(hipMemcpyAsync(d_tiles, chunk.data(), chunk.size() * sizeof(TileRec), hipMemcpyHostToDevice, s->stream));
 		hipLaunchKernelGGL(k_init_slots, dim3(uint32_t(chunk.size())), dim3(256), 0, s->stream, d_tiles, cam->film_width, rb);
 
-		const dim3 block(256), grid_slots((ns + 255) / 256), grid_items((2 * uint64_t(ns) + 255) / 256);
+		const uint32_t np = uint32_t(n_paths);
+		const dim3 block(256), grid_slots((ns + 255) / 256), grid_items((2 * n_paths + 255) / 256);
 		// Small batches (a 256x256 film is 65k paths, 8 waves per CU) do not fill the replenishing kernel's
 		// waves for long enough to pay for its set-up launches: they keep one ray per lane.
-		const bool persistent = scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && ns >= (1u << 18);
-		for (uint32_t k = 0; k < max_samples; k++) {
+		const bool persistent = scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && np >= (1u << 18);
+		for (uint32_t k = 0; k < max_samples; k += group) {
 			PTX_HIP(hipMemsetAsync(rb.counts, 0, 256, s->stream));
-			hipLaunchKernelGGL(k_raygen, dim3((ns + RAYGEN_BLOCK - 1) / RAYGEN_BLOCK), dim3(RAYGEN_BLOCK), 0, s->stream, rb, ns, k, cr, key0, key1, rb.active[0], rb.counts + 0);
+			hipLaunchKernelGGL(k_raygen, dim3((np + RAYGEN_BLOCK - 1) / RAYGEN_BLOCK), dim3(RAYGEN_BLOCK), 0, s->stream, rb, k, cr, key0, key1, rb.active[0], rb.counts + 0);
 			int cur = 0;
 			// A camera ray of depth D has at most D+1 vertices on its main path (depths D..0): the
 			// vertex of depth 0 never scatters, so after D+1 rounds no path is alive and every
 			// direct ray (written in round r, used at the start of round r+1) has been consumed.
 			for (uint32_t round = 0; round <= cam->film_max_ray_depth; round++) {
 				if (persistent) {
-					if (int rc = launch_scene_persistent(s, RenderIO{rb, rb.active[cur], rb.counts + cur, round == 0 ? 1u : 2u}, 2 * uint64_t(ns))) return rc;
+					if (int rc = launch_scene_persistent(s, RenderIO{rb, rb.active[cur], rb.counts + cur, round == 0 ? 1u : 2u}, 2 * n_paths)) return rc;
 				} else {
 					hipLaunchKernelGGL(k_extend<MODE_CULLED>, grid_items, block, 0, s->stream, s->rec, rb, rb.active[cur], rb.counts + cur);
 				}
 				PTX_HIP(hipMemsetAsync(rb.counts + (cur ^ 1), 0, sizeof(uint32_t), s->stream));
 				const bool delta = s->shade.n_delta_lights != 0;
 				const auto shade = delta ? k_shade<MODE_CULLED, true> : k_shade<MODE_CULLED, false>;
-				hipLaunchKernelGGL(shade, dim3((ns + shade_block(delta) - 1) / shade_block(delta)), dim3(shade_block(delta)), 0, s->stream, s->rec, s->shade, rb, rb.active[cur], rb.counts + cur, key0, key1,
+				hipLaunchKernelGGL(shade, dim3((np + shade_block(delta) - 1) / shade_block(delta)), dim3(shade_block(delta)), 0, s->stream, s->rec, s->shade, rb, rb.active[cur], rb.counts + cur, key0, key1,
 				                   rb.active[cur ^ 1], rb.counts + (cur ^ 1));
 				cur ^= 1;
 			}
+			hipLaunchKernelGGL(k_sum_pass, grid_slots, block, 0, s->stream, rb, k);
 		}
 		hipLaunchKernelGGL(k_flush, grid_slots, block, 0, s->stream, rb, ns, d_accum, d_samples);
 		PTX_HIP(hipGetLastError());

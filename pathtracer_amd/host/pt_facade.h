@@ -303,7 +303,7 @@ public:
 private:
 	bool scene_use_bvh = true;
 	int device = 0;
-	uint32_t seed = 1, tiles_per_batch = 64;
+	uint32_t seed = 1, tiles_per_batch = 128;   // 128 tiles of 100x100x50 = 64 M paths, one pass of the library
 	ptx_scene_t scene = nullptr;
 	PtxCamera camera{};
 	std::vector<PtxTile> tiles;

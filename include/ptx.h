@@ -265,6 +265,21 @@ typedef struct PtxTile {                     /* Pathtracer::Tile, pathtracer.cpp
 int ptx_render_tiles(ptx_scene_t scene, const PtxCamera* camera, const PtxTile* tiles, uint32_t n_tiles, uint64_t seed,
                      int64_t* accum_rgb, uint32_t* samples, uint32_t flags);
 
+/* Pathtracer::accumulator / accumulator_samples (pathtracer.h:80-83) kept on the scene's GPU between
+ * calls, so that a render made of many ptx_render_tiles calls (the reference reports progress tile by
+ * tile, pathtracer.cpp:568-584) moves the film across PCIe only when somebody looks at it.
+ * ptx_frame_create gives a zeroed accumulator of width x height pixels; its device arrays go to
+ * ptx_render_tiles with PTX_MEM_DEVICE.  upload/download copy the whole film from/to host arrays of
+ * 3*width*height int64 and width*height uint32 (upload: render(..., add_samples = true) continuing
+ * a host-side accumulator, pathtracer.cpp:504-519) and return after the copy has completed. */
+typedef struct PtxFrame* ptx_frame_t;
+int ptx_frame_create(ptx_scene_t scene, uint32_t width, uint32_t height, ptx_frame_t* out);
+int64_t* ptx_frame_accum(ptx_frame_t frame);      /* device pointer, int64[3*width*height] */
+uint32_t* ptx_frame_samples(ptx_frame_t frame);   /* device pointer, uint32[width*height] */
+int ptx_frame_upload(ptx_frame_t frame, const int64_t* accum_rgb, const uint32_t* samples);
+int ptx_frame_download(ptx_frame_t frame, int64_t* accum_rgb, uint32_t* samples);
+void ptx_frame_destroy(ptx_frame_t frame);
+
 /* Pathtracer::render's tile list (pathtracer.cpp:522-563): 100x100-pixel x 50-sample tiles,
  * seeded from one mt19937(fixed_seed) in y, x, s order, stably sorted centre-out then by
  * s_begin.  Returns the tile count; writes at most `cap` tiles when `out` is non-null. */

@@ -514,3 +514,56 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 	if (!(flags & PTX_ASYNC) || host) PTX_HIP(hipStreamSynchronize(s->stream));
 	return PTX_OK;
 }
+
+// ------------------------------------------------------------------ device-resident film
+struct PtxFrame {
+	PtxScene* scene;
+	size_t n_pixels;
+	int64_t* accum;
+	uint32_t* samples;
+};
+
+extern "C" int ptx_frame_create(ptx_scene_t s, uint32_t width, uint32_t height, ptx_frame_t* out) {
+	if (!s || !out || !width || !height) return fail(PTX_ERR_INVALID, "ptx_frame_create: null argument or empty film");
+	PTX_HIP(hipSetDevice(s->device));
+	PtxFrame* f = new PtxFrame{s, size_t(width) * height, nullptr, nullptr};
+	const size_t a_bytes = f->n_pixels * 3 * sizeof(int64_t), s_bytes = f->n_pixels * sizeof(uint32_t);
+	void* p = nullptr;
+	if (hipMalloc(&p, a_bytes + s_bytes) != hipSuccess) {
+		delete f;
+		return fail(PTX_ERR_OOM, "ptx_frame_create: out of device memory");
+	}
+	f->accum = static_cast<int64_t*>(p);
+	f->samples = reinterpret_cast<uint32_t*>(static_cast<char*>(p) + a_bytes);
+	if (hipMemsetAsync(p, 0, a_bytes + s_bytes, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) {
+		(void)hipFree(p);
+		delete f;
+		return fail(PTX_ERR_DEVICE, "ptx_frame_create: clearing the film failed");
+	}
+	*out = f;
+	return PTX_OK;
+}
+extern "C" int64_t* ptx_frame_accum(ptx_frame_t f) { return f ? f->accum : nullptr; }
+extern "C" uint32_t* ptx_frame_samples(ptx_frame_t f) { return f ? f->samples : nullptr; }
+extern "C" int ptx_frame_upload(ptx_frame_t f, const int64_t* accum_rgb, const uint32_t* samples) {
+	if (!f || !accum_rgb || !samples) return fail(PTX_ERR_INVALID, "ptx_frame_upload: null argument");
+	PTX_HIP(hipSetDevice(f->scene->device));
+	PTX_HIP(hipMemcpyAsync(f->accum, accum_rgb, f->n_pixels * 3 * sizeof(int64_t), hipMemcpyHostToDevice, f->scene->stream));
+	PTX_HIP(hipMemcpyAsync(f->samples, samples, f->n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, f->scene->stream));
+	PTX_HIP(hipStreamSynchronize(f->scene->stream));
+	return PTX_OK;
+}
+extern "C" int ptx_frame_download(ptx_frame_t f, int64_t* accum_rgb, uint32_t* samples) {
+	if (!f || !accum_rgb || !samples) return fail(PTX_ERR_INVALID, "ptx_frame_download: null argument");
+	PTX_HIP(hipSetDevice(f->scene->device));
+	PTX_HIP(hipMemcpyAsync(accum_rgb, f->accum, f->n_pixels * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, f->scene->stream));
+	PTX_HIP(hipMemcpyAsync(samples, f->samples, f->n_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, f->scene->stream));
+	PTX_HIP(hipStreamSynchronize(f->scene->stream));
+	return PTX_OK;
+}
+extern "C" void ptx_frame_destroy(ptx_frame_t f) {
+	if (!f) return;
+	(void)hipSetDevice(f->scene->device);
+	(void)hipFree(f->accum);
+	delete f;
+}

@@ -12,6 +12,7 @@
 // scene descriptor (PtxSceneDesc, e.g. from ptx_js3d_load) instead of a ::Scene; errors are C++
 // exceptions (PT::Error) carrying ptx_last_error() instead of an abort.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -234,6 +235,7 @@ public:
 	void set_device(int d) { device = d; }
 	void set_seed(uint32_t fixed_seed) { seed = fixed_seed; }   // RNG::fixed_seed (util/rand.cpp), main.cpp:66
 	void set_tiles_per_batch(uint32_t n) { tiles_per_batch = n ? n : 1; }
+	void set_report_interval(float seconds) { report_interval = seconds; }   // 0: a report (and a film read-back) after every batch
 
 	// build_scene(Scene&) (pathtracer.cpp:182-387) from the flattened descriptor
 	void build_scene(const PtxSceneDesc& in) {
@@ -267,16 +269,30 @@ public:
 		running = true;
 		render_start = std::chrono::steady_clock::now();
 		worker = std::thread([this] {
-			for (uint32_t begin = 0; begin < total_tiles; begin += tiles_per_batch) {
+			// The film stays on the GPU for the whole render; it comes back for a progress report (at most
+			// one per report interval) and when the render ends or is cancelled.
+			ptx_frame_t frame = nullptr;
+			bool ok = ptx_frame_create(scene, camera.film_width, camera.film_height, &frame) == PTX_OK &&
+			          ptx_frame_upload(frame, accumulator.data(), accumulator_samples.data()) == PTX_OK;
+			auto last_report = std::chrono::steady_clock::now();
+			for (uint32_t begin = 0; ok && begin < total_tiles; begin += tiles_per_batch) {
 				if ((cancel_flag && *cancel_flag) || stop) break;
 				const uint32_t n = std::min(tiles_per_batch, total_tiles - begin);
-				if (ptx_render_tiles(scene, &camera, tiles.data() + begin, n, seed, accumulator.data(), accumulator_samples.data(), 0) != PTX_OK) {
-					failed = ptx_last_error();
-					break;
-				}
+				ok = ptx_render_tiles(scene, &camera, tiles.data() + begin, n, seed, ptx_frame_accum(frame), ptx_frame_samples(frame), PTX_MEM_DEVICE) == PTX_OK;
+				if (!ok) break;
 				traced_tiles += n;
-				if (report_fn) report_fn(Render_Report{float(traced_tiles) / float(total_tiles), accumulator_to_image()});
+				const auto now = std::chrono::steady_clock::now();
+				const bool last = begin + n >= total_tiles;
+				if (report_fn && (last || std::chrono::duration<float>(now - last_report).count() >= report_interval)) {
+					ok = ptx_frame_download(frame, accumulator.data(), accumulator_samples.data()) == PTX_OK;
+					if (!ok) break;
+					report_fn(Render_Report{float(traced_tiles) / float(total_tiles), accumulator_to_image()});
+					last_report = now;
+				}
 			}
+			if (ok && frame) ok = ptx_frame_download(frame, accumulator.data(), accumulator_samples.data()) == PTX_OK;
+			if (!ok) failed = ptx_last_error();
+			ptx_frame_destroy(frame);
 			render_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - render_start).count();
 			running = false;
 		});
@@ -292,6 +308,8 @@ public:
 		wait();
 		stop = false;
 	}
+	uint32_t samples_per_pixel_min() const { return accumulator_samples.empty() ? 0u : *std::min_element(accumulator_samples.begin(), accumulator_samples.end()); }
+	uint32_t samples_per_pixel_max() const { return accumulator_samples.empty() ? 0u : *std::max_element(accumulator_samples.begin(), accumulator_samples.end()); }
 	HDR_Image accumulator_to_image() const {   // pathtracer.cpp:429-442
 		HDR_Image img;
 		img.w = camera.film_width, img.h = camera.film_height;
@@ -316,7 +334,7 @@ private:
 	std::function<void(Render_Report&&)> report_fn;
 	std::thread worker;
 	std::chrono::steady_clock::time_point render_start;
-	float build_seconds = 0.0f, render_seconds = 0.0f;
+	float build_seconds = 0.0f, render_seconds = 0.0f, report_interval = 0.25f;
 	std::string failed;
 };
 

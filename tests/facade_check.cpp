@@ -55,6 +55,69 @@ int main(int argc, char** argv) {
 		std::vector<PT::Ray> batch(1000, PT::Ray({0.25f, 0.25f, 5.0f}, {0, 0, -1}));
 		for (const PT::Trace& b : mesh.hit_batch(batch)) EXPECT(b.hit && std::fabs(b.distance - 1.0f) < 1e-6f);
 	}
+	// PT::Pathtracer::render (pathtracer.cpp:491-584): an emissive square above a diffuse floor, camera looking
+	// down at the floor.  Asynchronous render with progress reports, then more samples on top, then a cancelled one.
+	{
+		const float quad[4 * 8] = {-1, 0, -1, 0, 1, 0, 0, 0, -1, 0, 1, 0, 1, 0, 0, 1, 1, 0, -1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 1};
+		const uint32_t quad_idx[6] = {0, 1, 2, 2, 1, 3};
+		PtxMeshDesc mesh{quad, 4, quad_idx, 2, 1, 0, nullptr, 0};
+		PtxTextureDesc tex[2] = {{PTX_TEX_CONSTANT, {0.8f, 0.8f, 0.8f}, 1.0f, 0, 0, 0, nullptr}, {PTX_TEX_CONSTANT, {1, 1, 1}, 5.0f, 0, 0, 0, nullptr}};
+		PtxMaterialDesc mat[2] = {{PTX_MAT_LAMBERTIAN, 0, -1, 1.0f}, {PTX_MAT_EMISSIVE, 1, -1, 1.0f}};
+		PtxInstanceDesc inst[2] = {};
+		const float floor_T[16] = {4, 0, 0, 0, 0, 1, 0, 0, 0, 0, 4, 0, 0, 0, 0, 1};                 // scale 4 in x and z (column major)
+		const float lamp_T[16] = {1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 0, 0, 3, 0, 1};               // turned over, 3 above the floor
+		inst[0].mesh = 0, inst[0].material = 0, std::memcpy(inst[0].T, floor_T, sizeof(floor_T));
+		inst[1].mesh = 0, inst[1].material = 1, std::memcpy(inst[1].T, lamp_T, sizeof(lamp_T));
+		PtxSceneDesc desc{};
+		desc.meshes = &mesh, desc.n_meshes = 1, desc.instances = inst, desc.n_instances = 2, desc.textures = tex, desc.n_textures = 2;
+		desc.materials = mat, desc.n_materials = 2, desc.use_bvh = 1;
+		PtxCamera cam{};
+		cam.vertical_fov = 60.0f, cam.aspect_ratio = 1.0f, cam.film_width = 250, cam.film_height = 250, cam.film_samples = 60, cam.film_max_ray_depth = 3;
+		const float cam_T[16] = {1, 0, 0, 0, 0, 0, -1, 0, 0, 1, 0, 0, 0, 2, 0, 1};                  // at height 2, looking down -y
+		std::memcpy(cam.camera_to_world, cam_T, sizeof(cam_T));
+
+		PT::Pathtracer pt;
+		pt.set_tiles_per_batch(4);      // 3x3 pixel tiles x 2 sample chunks = 18 tiles: five batches
+		pt.set_report_interval(0.0f);
+		std::vector<float> progress;
+		double last_mean = 0.0;
+		bool quit = false;
+		pt.render(desc, cam, [&](PT::Pathtracer::Render_Report&& r) {
+			progress.push_back(r.first);
+			double m = 0.0;
+			for (float v : r.second.rgb) m += v;
+			last_mean = m / double(r.second.rgb.size());
+		}, &quit);
+		pt.wait();
+		EXPECT(pt.error().empty() && !pt.in_progress());
+		EXPECT(progress.size() == 5 && progress.back() == 1.0f);
+		for (size_t k = 1; k < progress.size(); k++) EXPECT(progress[k] > progress[k - 1]);
+		EXPECT(last_mean > 0.05 && last_mean < 5.0);
+		const double first_mean = last_mean;
+		PT::HDR_Image img = pt.accumulator_to_image();
+		EXPECT(img.w == 250 && img.h == 250 && img.rgb.size() == 250u * 250u * 3u);
+
+		// add_samples: the same film gets 60 more samples per pixel; the estimate stays where it was
+		progress.clear();
+		pt.render(desc, cam, [&](PT::Pathtracer::Render_Report&& r) {
+			progress.push_back(r.first);
+			double m = 0.0;
+			for (float v : r.second.rgb) m += v;
+			last_mean = m / double(r.second.rgb.size());
+		}, &quit, true);
+		pt.wait();
+		EXPECT(pt.error().empty() && progress.back() == 1.0f);
+		EXPECT(pt.samples_per_pixel_min() == 120u && pt.samples_per_pixel_max() == 120u);
+		EXPECT(std::fabs(last_mean - first_mean) < 0.05 * first_mean);
+
+		// quit set before the first batch: nothing is traced, the film is cleared (no add_samples) and stays empty
+		quit = true;
+		progress.clear();
+		pt.render(desc, cam, [&](PT::Pathtracer::Render_Report&& r) { progress.push_back(r.first); }, &quit);
+		pt.wait();
+		EXPECT(pt.error().empty() && progress.empty());
+		EXPECT(pt.samples_per_pixel_max() == 0u);
+	}
 	std::printf("facade gpu checks passed\n");
 	return 0;
 }

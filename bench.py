@@ -181,6 +181,12 @@ def main():
                     help="run the multi-rank code path on fewer GPUs than ranks: gloo collectives, rank r on device r %% device_count (a functional check, not a measurement)")
     args = ap.parse_args()
 
+    # Exactly one line goes to stdout, the result: native libraries print there too (RCCL announces its path
+    # at start-up), so file descriptor 1 points at stderr until the result is written.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from pathtracer_amd import abi, capi, synth
 
@@ -364,7 +370,8 @@ def main():
                                           "visit counts from the CPU checker) per launch / dominant-kernel time; the culled traversal that produces the same "
                                           "results fetches far less (culled_traversal), and the 91 MB working set stays in L2 / Infinity Cache, so neither "
                                           "figure is DRAM traffic -- see traffic"}
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
     scene.close()
     if dist is not None:
         dist.destroy_process_group()

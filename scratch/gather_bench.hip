@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_gather(const float4* __restrict__ table
 		}
 		const uint32_t h = __float_as_uint(q0.x) ^ __float_as_uint(q1.y) ^ __float_as_uint(q2.z) ^ __float_as_uint(q3.w);
 		acc += h;
-		idx = mix(h + it) % n;
+		idx = mix(h + it + (blockIdx.x * 256u + threadIdx.x) * 0x9E3779B9u) % n;   // lane-dependent: chains of different lanes never merge
 	}
 	out[blockIdx.x * 256u + threadIdx.x] = acc;
 }

@@ -43,9 +43,13 @@ if "FETCH_SIZE" in cnt:
         "command": "rocprofv3 --pmc <counters> -- python3 scratch/prof_closest.py 16777216 2 c   (one pass per counter group: scratch/profile.sh, scratch/pmc_sq.sh)",
         "FETCH_SIZE_KB_per_launch": cnt["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": cnt.get("WRITE_SIZE"),
         "TCC_HIT_sum": hit, "TCC_MISS_sum": miss, "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
-        "correction": "FETCH_SIZE is tallied at 64 B per 128-B request on gfx950: doubled; WRITE_SIZE taken as is; KB = 1024 B. The counters sit on the L2's fabric side, so Infinity Cache hits are included: with a 69 MB working set this is an upper bound on DRAM traffic, not DRAM traffic.",
-        "closest_culled_hbm_bytes_per_launch": (2.0 * cnt["FETCH_SIZE"] + cnt.get("WRITE_SIZE", 0.0)) * 1024.0,
-        "uncorrected_bytes_per_launch": (cnt["FETCH_SIZE"] + cnt.get("WRITE_SIZE", 0.0)) * 1024.0,
+        "correction": "KB = 1024 B.  FETCH_SIZE = 64 B per L2 read miss.  The guide's gfx950 rule (double FETCH_SIZE) holds for wide coalesced streaming reads, "
+                      "whose 128-B requests are tallied at 64 B; this kernel reads one 64-byte node or 48-byte triangle record per lane, and on that pattern "
+                      "the counter was calibrated against a known byte count (profiles/r01_fetch_calibration.json: 13.42 GB of random 64-B records requested, "
+                      "FETCH_SIZE 13.78 GB): taken as is.  WRITE_SIZE taken as is.  The counters sit on the L2's fabric side, so Infinity Cache hits are included: "
+                      "with a 69 MB working set this is an upper bound on DRAM traffic, not DRAM traffic.",
+        "closest_culled_hbm_bytes_per_launch": (cnt["FETCH_SIZE"] + cnt.get("WRITE_SIZE", 0.0)) * 1024.0,
+        "bytes_per_launch_if_fetch_size_were_doubled": (2.0 * cnt["FETCH_SIZE"] + cnt.get("WRITE_SIZE", 0.0)) * 1024.0,
     }
     json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 if "SQ_INSTS_VALU" in cnt and "GRBM_GUI_ACTIVE" in cnt:

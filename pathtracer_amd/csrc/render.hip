@@ -54,7 +54,7 @@ struct alignas(16) PathState {            // 64 bytes per path
 	uint32_t draws;           // random numbers consumed so far
 	float Wd[3];              // weight of the pending direct ray's emission (T * attenuation [/ pdf])
 	uint32_t flags;
-	uint32_t sample, pad[3];
+	uint32_t sample, pixel, pad[2];   // which sample of which film pixel (the random stream's name)
 };
 
 struct TileRec {
@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(RAYGEN_BLOCK) k_raygen(RenderBuffers rb, uint3
 			ps.draws = rng.draws;
 			ps.flags = FLAG_CAMERA;
 			ps.sample = si.s_begin + k;
+			ps.pixel = si.pixel;
 			store_rec(rb.paths + path, ps);
 			store_rec(rb.rays + 2 * path, PtxRay{{r.ox, r.oy, r.oz}, {r.dx, r.dy, r.dz}, r.tmin, r.tmax});
 		}
@@ -273,15 +274,31 @@ __global__ void __launch_bounds__(shade_block(DELTA)) k_shade(SceneRec sc, Shade
 
 		// ---- the direct ray traced last round: trace(rng, new_in_ray).first (pathtracer.cpp:71-76)
 		if (ps.flags & FLAG_HAS_DIRECT) {
-			const PtxRay dr = load_rec(rb.rays + 2 * slot + 1);
+			// the direct ray itself is read back only where its direction or origin matters
 			const HitRec dh = load_rec(rb.hits + 2 * slot + 1);
 			V3f first = v3(0, 0, 0);
 			if (dh.prim == 0xFFFFFFFFu) {
-				first = env_radiance(sh, v3(dr.d[0], dr.d[1], dr.d[2]));   // pathtracer.cpp:129-136
+				if (sh.n_env_lights) {   // pathtracer.cpp:129-136
+					const PtxRay dr = load_rec(rb.rays + 2 * slot + 1);
+					first = env_radiance(sh, v3(dr.d[0], dr.d[1], dr.d[2]));
+				}
 			} else {
-				const Ray3 r{dr.o[0], dr.o[1], dr.o[2], dr.d[0], dr.d[1], dr.d[2], dr.tmin, dr.tmax};
-				const Surface s = rebuild_surface(sc, sh, r, dh);
-				if (s.material >= 0) first = bsdf_emission(sh, sh.materials[s.material], s.u, s.v);   // depth 0: {emissive, {}} (pathtracer.cpp:160-163)
+				// depth 0: {emissive, {}} (pathtracer.cpp:160-163).  Only an emissive surface with an image texture
+				// needs the hit rebuilt (for its uv); everything else is decided by the instance's material.
+				const int32_t mat_id = sc.insts[dh.inst].material;
+				if (mat_id >= 0) {
+					const MatRec dm = sh.materials[mat_id];
+					if (dm.type == PTX_MAT_EMISSIVE) {
+						if (sh.textures[dm.tex_a].type == PTX_TEX_CONSTANT) {
+							first = tex_evaluate(sh, dm.tex_a, 0.0f, 0.0f);
+						} else {
+							const PtxRay dr = load_rec(rb.rays + 2 * slot + 1);
+							const Ray3 r{dr.o[0], dr.o[1], dr.o[2], dr.d[0], dr.d[1], dr.d[2], dr.tmin, dr.tmax};
+							const Surface s = rebuild_surface(sc, sh, r, dh);
+							first = bsdf_emission(sh, dm, s.u, s.v);
+						}
+					}
+				}
 			}
 			L = L + first * v3(ps.Wd[0], ps.Wd[1], ps.Wd[2]);
 		}
@@ -321,7 +338,7 @@ __global__ void __launch_bounds__(shade_block(DELTA)) k_shade(SceneRec sc, Shade
 					}
 				}
 				PathRng rng;
-				rng.start(key0, key1, rb.slots[slot % rb.n_slots].pixel, ps.sample, ps.draws);
+				rng.start(key0, key1, ps.pixel, ps.sample, ps.draws);
 				// sample_direct_lighting_task4 (pathtracer.cpp:34-78): weight = attenuation [/ pdf]
 				{
 					const ScatterRec sc1 = bsdf_scatter(sh, m, rng, out_dir, s.u, s.v);

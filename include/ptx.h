@@ -232,6 +232,21 @@ int ptx_trace_closest(ptx_scene_t scene, const PtxRay* rays, uint64_t n, PtxHit*
  * computed with early exit on the first accepted triangle. */
 int ptx_trace_any(ptx_scene_t scene, const PtxRay* rays, uint64_t n, uint8_t* occluded, uint32_t flags);
 
+/* ptx_trace_closest for callers that cannot allocate -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same results as
+ * ptx_trace_closest bit for bit; the kernels' working buffers (ray-grouping keys and order, claim
+ * counters, the list of rays set aside for the plain-division kernel) come from a fixed device array
+ * that the library holds on every GPU it runs on (about 20 MB), so the call performs no hipMalloc /
+ * hipFree and creates no events (it is not recorded by ptx_get_kernel_times).
+ * Restrictions: rays, hits, bary and inst must be device pointers (PTX_MEM_DEVICE is required);
+ * n <= PTX_NOALLOC_MAX_RAYS, larger batches are rejected with PTX_ERR_INVALID.  All calls on one GPU
+ * share that GPU's array: two calls that overlap in time on the same GPU (different streams or
+ * scenes) race; issue them on one stream, or wait for one before starting the next. */
+#define PTX_NOALLOC_MAX_RAYS (1ull << 20)
+int ptx_trace_closest_noalloc(ptx_scene_t scene, const PtxRay* rays, uint64_t n, PtxHit* hits, float* bary, uint32_t* inst,
+                              uint32_t flags);
+uint64_t ptx_noalloc_max_rays(void);
+
 /* Diagnostics (no counterpart in the reference).  ptx_trace_closest_stats: the closest-hit
  * traversal instrumented; stats3[3*i + {0,1,2}] = interior nodes fetched (two box tests each; low
  * 24 bits, the high 8 bits hold the deepest traversal stack), leaves entered, triangles tested

@@ -61,6 +61,9 @@ def lib():
     L.ptx_scene_mesh_get_order.argtypes = [vp, C.c_uint32, vp]
     L.ptx_scene_get_instance_order.argtypes = [vp, vp]
     L.ptx_trace_closest.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint32]
+    L.ptx_trace_closest_noalloc.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint32]
+    L.ptx_noalloc_max_rays.restype = C.c_uint64
+    L.ptx_noalloc_max_rays.argtypes = []
     L.ptx_trace_any.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32]
     L.ptx_trace_closest_stats.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32]
     L.ptx_selftest_division.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -213,6 +216,12 @@ class Scene:
         """Torch CUDA tensors in and out (nothing is copied): rays uint8/float32 view of PtxRay[n], hits of PtxHit[n]."""
         n = n if n is not None else rays.numel() * rays.element_size() // 32
         check(lib().ptx_trace_closest(self.h, rays.data_ptr(), n, hits.data_ptr(), _addr(bary)[0], _addr(inst)[0], flags | abi.PTX_MEM_DEVICE))
+
+    def trace_closest_noalloc(self, rays, hits, bary=None, inst=None, flags=abi.PTX_MEM_DEVICE, n=None):
+        """ptx_trace_closest_noalloc: torch CUDA tensors in and out; the library allocates nothing.  `flags` is passed
+        as given (PTX_MEM_DEVICE is required by the entry point)."""
+        n = n if n is not None else rays.numel() * rays.element_size() // 32
+        check(lib().ptx_trace_closest_noalloc(self.h, rays.data_ptr(), n, hits.data_ptr(), _addr(bary)[0], _addr(inst)[0], flags))
 
     def trace_closest_stats(self, rays, flags=0):
         """Per ray: interior nodes fetched, leaves entered, triangles tested, deepest traversal stack."""

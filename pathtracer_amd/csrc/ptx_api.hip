@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <random>
 #include <string>
 #include <vector>
@@ -351,6 +352,43 @@ static int finish_geometry(PtxScene* s, SceneBuild& sb) {
 	return PTX_OK;
 }
 
+// ------------------------------------------------------------------ fixed device scratch (ptx_trace_closest_noalloc)
+// Callers that may not allocate (HIP graph capture, tight serving loops) get the replenishing kernel's
+// working buffers from this file-scope device array instead of hipMalloc: every GPU the library runs on
+// holds one copy until the process ends.  Layout for up to NOALLOC_MAX_RAYS rays:
+//   [counters 1 KB][slow list n][keys 2n][indices 2n][table + chunk totals]     (n in uint32)
+constexpr uint64_t NOALLOC_MAX_RAYS = PTX_NOALLOC_MAX_RAYS;
+constexpr size_t noalloc_table_words() {
+	return size_t((SORT_DIGITS * uint32_t((NOALLOC_MAX_RAYS + SORT_TILE - 1) / SORT_TILE) + SCAN_CHUNK - 1) / SCAN_CHUNK) * (SCAN_CHUNK + 1);
+}
+constexpr size_t NOALLOC_OFF_SLOW = COUNTER_BLOCK_BYTES;
+constexpr size_t NOALLOC_OFF_KEYS = NOALLOC_OFF_SLOW + NOALLOC_MAX_RAYS * 4;
+constexpr size_t NOALLOC_OFF_IDX = NOALLOC_OFF_KEYS + NOALLOC_MAX_RAYS * 8;
+constexpr size_t NOALLOC_OFF_TABLE = NOALLOC_OFF_IDX + NOALLOC_MAX_RAYS * 8;
+constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_OFF_TABLE + noalloc_table_words() * 4;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+// The array's address on each device.  In host code the name `scratch` is only a handle for
+// hipGetSymbolAddress -- never an address a kernel may be given -- and every GPU has its own copy at
+// its own address, so the lookup runs once per device, with that device current, when the first scene
+// is created there (scene creation is this library's per-device set-up step).
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::mutex g_noalloc_mutex;
+static unsigned char* g_noalloc_ptr[NOALLOC_MAX_DEVICES] = {};
+
+static int noalloc_scratch_for_device(int device, unsigned char** out) {
+	*out = nullptr;
+	if (device < 0 || device >= NOALLOC_MAX_DEVICES) return PTX_OK;   // such a device simply has no allocation-free path
+	std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+	if (!g_noalloc_ptr[device]) {
+		void* p = nullptr;
+		PTX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+		g_noalloc_ptr[device] = static_cast<unsigned char*>(p);
+	}
+	*out = g_noalloc_ptr[device];
+	return PTX_OK;
+}
+
 static int open_device(int device, PtxScene** out) {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PTX_ERR_NO_DEVICE, "no HIP device visible");
@@ -361,6 +399,11 @@ static int open_device(int device, PtxScene** out) {
 	int cus = 0;
 	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
 	(*out)->cu_count = uint32_t(cus);
+	if (int rc = noalloc_scratch_for_device(device, &(*out)->noalloc_scratch)) {
+		delete *out;
+		*out = nullptr;
+		return rc;
+	}
 	return PTX_OK;
 }
 
@@ -402,21 +445,35 @@ int scene_counter_block(PtxScene* s, unsigned long long** out) {
 }
 static int grow_scratch(PtxScene* s, int slot, size_t bytes) { return scene_scratch(s, slot, bytes); }
 
+// Table length of the grouping pass for n rays: the digit-major table of per-tile counts, padded with
+// zeros to whole scan chunks, followed by the chunk totals.
+static void sort_table_shape(uint64_t n, uint32_t& n_tiles, uint32_t& n_chunks, uint32_t& table_len) {
+	n_tiles = uint32_t((n + SORT_TILE - 1) / SORT_TILE);
+	n_chunks = (SORT_DIGITS * n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+	table_len = n_chunks * SCAN_CHUNK;
+}
+
+// Device buffers of one replenishing-kernel launch: the scene's grown-on-demand scratch for the
+// ordinary entry points, slices of the fixed device array for the allocation-free one.
+struct PersistentBuffers {
+	unsigned long long* counters;   // COUNTER_BLOCK_BYTES, zeroed by the launch
+	uint32_t* slow_list;            // n entries: rays deferred to the plain-division kernel
+	uint32_t* keys;                 // 2n: keys, keys after pass 0          (grouping pass only)
+	uint32_t* idx;                  // 2n: indices after pass 0, final order (grouping pass only)
+	uint32_t* table;                // table_len + n_chunks of sort_table_shape(n)
+	bool timed;                     // record the launch in the scene's ring of HIP events
+};
+
 // Groups the batch by origin cell and direction octant (raysort.hip.h); *order receives the
 // device array of ray indices in that order.
-static int sort_rays(PtxScene* s, const PtxRay* d_rays, uint64_t n, const uint32_t** order) {
-	const uint32_t n_tiles = uint32_t((n + SORT_TILE - 1) / SORT_TILE);
-	// digit-major table of per-tile counts, padded with zeros to whole scan chunks, then the chunk totals
-	const uint32_t n_chunks = (SORT_DIGITS * n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
-	const uint32_t table_len = n_chunks * SCAN_CHUNK;
-	if (int rc = grow_scratch(s, 4, 2 * n * sizeof(uint32_t))) return rc;           // keys, keys after pass 0
-	if (int rc = grow_scratch(s, 5, 2 * n * sizeof(uint32_t))) return rc;           // indices after pass 0, final order
-	if (int rc = grow_scratch(s, 6, (size_t(table_len) + n_chunks) * sizeof(uint32_t))) return rc;
-	uint32_t* keys0 = static_cast<uint32_t*>(s->scratch[4]);
+static int sort_rays(PtxScene* s, const PtxRay* d_rays, uint64_t n, const PersistentBuffers& pb, const uint32_t** order) {
+	uint32_t n_tiles, n_chunks, table_len;
+	sort_table_shape(n, n_tiles, n_chunks, table_len);
+	uint32_t* keys0 = pb.keys;
 	uint32_t* keys1 = keys0 + n;
-	uint32_t* idx1 = static_cast<uint32_t*>(s->scratch[5]);
+	uint32_t* idx1 = pb.idx;
 	uint32_t* ord = idx1 + n;
-	uint32_t* table = static_cast<uint32_t*>(s->scratch[6]);
+	uint32_t* table = pb.table;
 	uint32_t* totals = table + table_len;
 	auto scan = [&]() {
 		hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(256), 0, s->stream, table, totals);
@@ -441,19 +498,39 @@ static int sort_rays(PtxScene* s, const PtxRay* d_rays, uint64_t n, const uint32
 	return PTX_OK;
 }
 
+static bool wants_grouping(bool sort, uint64_t n) { return sort && n >= (1u << 16) && n < (uint64_t(1) << 32); }
+
+// The scene's own buffers for a launch over n rays, grown where too small.
+static int scene_persistent_buffers(PtxScene* s, bool sort, uint64_t n, PersistentBuffers& pb) {
+	pb = PersistentBuffers{};
+	pb.timed = true;
+	if (wants_grouping(sort, n)) {
+		uint32_t n_tiles, n_chunks, table_len;
+		sort_table_shape(n, n_tiles, n_chunks, table_len);
+		if (int rc = grow_scratch(s, 4, 2 * n * sizeof(uint32_t))) return rc;
+		if (int rc = grow_scratch(s, 5, 2 * n * sizeof(uint32_t))) return rc;
+		if (int rc = grow_scratch(s, 6, (size_t(table_len) + n_chunks) * sizeof(uint32_t))) return rc;
+		pb.keys = static_cast<uint32_t*>(s->scratch[4]);
+		pb.idx = static_cast<uint32_t*>(s->scratch[5]);
+		pb.table = static_cast<uint32_t*>(s->scratch[6]);
+	}
+	if (int rc = scene_counter_block(s, &pb.counters)) return rc;
+	if (int rc = grow_scratch(s, 7, n * sizeof(uint32_t))) return rc;
+	pb.slow_list = static_cast<uint32_t*>(s->scratch[7]);
+	return PTX_OK;
+}
+
 template<bool ANY>
-static int launch_persistent(PtxScene* s, bool culled, bool sort, const PtxRay* d_rays, uint64_t n, PtxHit* d_hits, float* d_bary, uint32_t* d_inst,
-                             uint8_t* d_occ) {
-	const uint32_t* order = nullptr;
-	if (sort && n >= (1u << 16) && n < (uint64_t(1) << 32))
-		if (int rc = sort_rays(s, d_rays, n, &order)) return rc;
-	unsigned long long* counters = nullptr;
-	if (int rc = scene_counter_block(s, &counters)) return rc;
-	PTX_HIP(hipMemsetAsync(s->next_ray, 0, COUNTER_BLOCK_BYTES, s->stream));
+static int launch_persistent(PtxScene* s, bool culled, bool sort, const PersistentBuffers& pb, const PtxRay* d_rays, uint64_t n, PtxHit* d_hits, float* d_bary,
+                             uint32_t* d_inst, uint8_t* d_occ) {
 	if (n >= (uint64_t(1) << 32)) return fail(PTX_ERR_INVALID, "ray count too large for one launch");
-	if (int rc = grow_scratch(s, 7, n * sizeof(uint32_t))) return rc;   // rays deferred to the plain-division kernel
-	uint32_t* slow_list = static_cast<uint32_t*>(s->scratch[7]);
-	uint32_t* slow_count = reinterpret_cast<uint32_t*>(s->next_ray) + 16;   // same zeroed 256-byte block, its own 64-byte line
+	const uint32_t* order = nullptr;
+	if (wants_grouping(sort, n))
+		if (int rc = sort_rays(s, d_rays, n, pb, &order)) return rc;
+	unsigned long long* const next_ray = pb.counters;
+	PTX_HIP(hipMemsetAsync(next_ray, 0, COUNTER_BLOCK_BYTES, s->stream));
+	uint32_t* slow_list = pb.slow_list;
+	uint32_t* slow_count = reinterpret_cast<uint32_t*>(next_ray) + 16;   // same zeroed block, its own 64-byte line
 	// enough 256-thread blocks to fill every CU at 8 waves per SIMD; each wave pulls rays until the pool is dry
 	const uint64_t want = (n + 255) / 256;
 	// Tuning knobs for experiments (not part of the ABI): blocks per CU and the refill threshold.
@@ -465,20 +542,24 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const PtxRay* 
 	static const unsigned long long wave_chunk = getenv("PTX_WAVE_CHUNK") ? std::max(1, atoi(getenv("PTX_WAVE_CHUNK"))) : WAVE_CHUNK;
 	const dim3 block(256), grid(uint32_t(std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu)))));
 	const uint32_t slot = uint32_t(s->timed_launches % PtxScene::TIMING_RING);
-	if (!s->t_start[slot]) {
-		PTX_HIP(hipEventCreate(&s->t_start[slot]));
-		PTX_HIP(hipEventCreate(&s->t_stop[slot]));
+	if (pb.timed) {
+		if (!s->t_start[slot]) {
+			PTX_HIP(hipEventCreate(&s->t_start[slot]));
+			PTX_HIP(hipEventCreate(&s->t_stop[slot]));
+		}
+		PTX_HIP(hipEventRecord(s->t_start[slot], s->stream));
 	}
-	PTX_HIP(hipEventRecord(s->t_start[slot], s->stream));
-	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
-	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, s->next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
-	PTX_HIP(hipEventRecord(s->t_stop[slot], s->stream));
-	s->timed_launches++;
+	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
+	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
+	if (pb.timed) {
+		PTX_HIP(hipEventRecord(s->t_stop[slot], s->stream));
+		s->timed_launches++;
+	}
 #ifdef PTX_PROFILE_LANES
 	{
 		unsigned long long h[32];
 		PTX_HIP(hipStreamSynchronize(s->stream));
-		PTX_HIP(hipMemcpy(h, s->next_ray, sizeof(h), hipMemcpyDeviceToHost));
+		PTX_HIP(hipMemcpy(h, next_ray, sizeof(h), hipMemcpyDeviceToHost));
 		std::fprintf(stderr, "[lanes] wave-iterations %llu, node phase ran in %llu with %.1f lanes, triangle phase ran in %llu with %.1f lanes, lanes holding a ray %.1f\n", h[16], h[19],
 		             double(h[17]) / double(h[19] ? h[19] : 1), h[20], double(h[18]) / double(h[20] ? h[20] : 1), double(h[21]) / double(h[16] ? h[16] : 1));
 	}
@@ -788,7 +869,9 @@ int ptx_trace_closest(ptx_scene_t s, const PtxRay* rays, uint64_t n, PtxHit* hit
 	const dim3 block(256), grid(uint32_t((n + 255) / 256));
 	const bool culled = (flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED;
 	if (use_persistent(s) && !(flags & PTX_NO_PERSISTENT)) {
-		if (int rc = launch_persistent<false>(s, culled, !(flags & PTX_RAYS_COHERENT), d_rays, n, d_hits, d_bary, d_inst, nullptr)) return rc;
+		PersistentBuffers pb;
+		if (int rc = scene_persistent_buffers(s, !(flags & PTX_RAYS_COHERENT), n, pb)) return rc;
+		if (int rc = launch_persistent<false>(s, culled, !(flags & PTX_RAYS_COHERENT), pb, d_rays, n, d_hits, d_bary, d_inst, nullptr)) return rc;
 	} else if (s->rec.mesh_only) {
 		if (culled) hipLaunchKernelGGL((k_trace_closest<MODE_CULLED, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
 		else hipLaunchKernelGGL((k_trace_closest<MODE_REFERENCE, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
@@ -805,6 +888,41 @@ int ptx_trace_closest(ptx_scene_t s, const PtxRay* rays, uint64_t n, PtxHit* hit
 		if (bary) PTX_HIP(hipMemcpyAsync(bary, d_bary, n * 2 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
 		if (inst) PTX_HIP(hipMemcpyAsync(inst, d_inst, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
 	}
+	if (!(flags & PTX_ASYNC)) PTX_HIP(hipStreamSynchronize(s->stream));
+	return PTX_OK;
+}
+
+uint64_t ptx_noalloc_max_rays(void) { return NOALLOC_MAX_RAYS; }
+
+int ptx_trace_closest_noalloc(ptx_scene_t s, const PtxRay* rays, uint64_t n, PtxHit* hits, float* bary, uint32_t* inst, uint32_t flags) {
+	if (!s || (n && (!rays || !hits))) return fail(PTX_ERR_INVALID, "ptx_trace_closest_noalloc: null argument");
+	if (!(flags & PTX_MEM_DEVICE)) return fail(PTX_ERR_INVALID, "ptx_trace_closest_noalloc: rays and hits must be device pointers (PTX_MEM_DEVICE); staging host buffers would allocate");
+	if (n > NOALLOC_MAX_RAYS) return fail(PTX_ERR_INVALID, "ptx_trace_closest_noalloc: " + std::to_string(n) + " rays exceed the fixed scratch array's limit of " + std::to_string(NOALLOC_MAX_RAYS) + " per call (split the batch, or use ptx_trace_closest)");
+	if (n == 0) return PTX_OK;
+	PTX_HIP(hipSetDevice(s->device));
+	const dim3 block(256), grid(uint32_t((n + 255) / 256));
+	const bool culled = (flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED;
+	if (use_persistent(s) && !(flags & PTX_NO_PERSISTENT)) {
+		unsigned char* base = s->noalloc_scratch;   // device address from hipGetSymbolAddress, not the array's name
+		if (!base) return fail(PTX_ERR_UNSUPPORTED, "ptx_trace_closest_noalloc: no fixed scratch array on this device");
+		PersistentBuffers pb;
+		pb.counters = reinterpret_cast<unsigned long long*>(base);
+		pb.slow_list = reinterpret_cast<uint32_t*>(base + NOALLOC_OFF_SLOW);
+		pb.keys = reinterpret_cast<uint32_t*>(base + NOALLOC_OFF_KEYS);
+		pb.idx = reinterpret_cast<uint32_t*>(base + NOALLOC_OFF_IDX);
+		pb.table = reinterpret_cast<uint32_t*>(base + NOALLOC_OFF_TABLE);
+		pb.timed = false;   // the timing ring creates HIP events on first use
+		if (int rc = launch_persistent<false>(s, culled, !(flags & PTX_RAYS_COHERENT), pb, rays, n, hits, bary, inst, nullptr)) return rc;
+	} else if (s->rec.mesh_only) {
+		// lists and trees outside the exact-division range: one ray per lane, no working buffers at all
+		if (culled) hipLaunchKernelGGL((k_trace_closest<MODE_CULLED, true>), grid, block, 0, s->stream, s->rec, rays, n, hits, bary, inst);
+		else hipLaunchKernelGGL((k_trace_closest<MODE_REFERENCE, true>), grid, block, 0, s->stream, s->rec, rays, n, hits, bary, inst);
+	} else {
+		if (culled) hipLaunchKernelGGL((k_trace_closest<MODE_CULLED, false>), grid, block, 0, s->stream, s->rec, rays, n, hits, bary, inst);
+		else hipLaunchKernelGGL((k_trace_closest<MODE_REFERENCE, false>), grid, block, 0, s->stream, s->rec, rays, n, hits, bary, inst);
+	}
+	PTX_HIP(hipGetLastError());
+	s->counters.rays_closest += n;
 	if (!(flags & PTX_ASYNC)) PTX_HIP(hipStreamSynchronize(s->stream));
 	return PTX_OK;
 }
@@ -828,7 +946,9 @@ int ptx_trace_any(ptx_scene_t s, const PtxRay* rays, uint64_t n, uint8_t* occlud
 	const dim3 block(256), grid(uint32_t((n + 255) / 256));
 	const bool culled = (flags & PTX_TRAVERSE_MASK) == PTX_TRAVERSE_CULLED;
 	if (use_persistent(s) && !(flags & PTX_NO_PERSISTENT)) {
-		if (int rc = launch_persistent<true>(s, culled, !(flags & PTX_RAYS_COHERENT), d_rays, n, nullptr, nullptr, nullptr, d_occ)) return rc;
+		PersistentBuffers pb;
+		if (int rc = scene_persistent_buffers(s, !(flags & PTX_RAYS_COHERENT), n, pb)) return rc;
+		if (int rc = launch_persistent<true>(s, culled, !(flags & PTX_RAYS_COHERENT), pb, d_rays, n, nullptr, nullptr, nullptr, d_occ)) return rc;
 	} else if (s->rec.mesh_only) {
 		if (culled) hipLaunchKernelGGL((k_trace_any<MODE_CULLED, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
 		else hipLaunchKernelGGL((k_trace_any<MODE_REFERENCE, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);

@@ -79,6 +79,7 @@ struct PtxScene {
 	uint32_t cu_count = 256;
 	bool persistent_ok = false;     // single tame BVH mesh: the replenishing kernel applies
 	unsigned long long* next_ray = nullptr;   // device counter of the replenishing kernel
+	unsigned char* noalloc_scratch = nullptr; // this device's copy of the fixed scratch array (ptx_trace_closest_noalloc)
 	uint64_t bytes_nodes = 0, bytes_tris = 0;
 	PtxCounters counters{};
 	// Scratch grown on demand (host-pointer calls, render state).

@@ -76,32 +76,9 @@ def cpu_baseline_and_counts(verts, idx, nodes, order, rays, target_seconds=12.0)
 
 
 def instanced_cow_scene(n):
-    """Config 5 stand-in: n^3 instances of the reference's 5,856-triangle cow mesh (10.1 M instanced triangles at
-    n = 12) on a grid, Lambertian, over a floor quad and under one emissive quad."""
-    from pathtracer_amd import abi
+    """Config 5: n^3 instances of the reference's 5,856-triangle cow mesh (10.1 M instanced triangles at n = 12)."""
     import scenes
-    g = np.load(os.path.join(ROOT, "tests", "golden", "scene_refract_cow_cbox.npz"), allow_pickle=False)
-    cow_i = max(range(int(g["n_meshes"])), key=lambda i: len(g[f"mesh{i}_indices"]))
-    sb = abi.SceneBuilder()
-    cow = sb.add_mesh(g[f"mesh{cow_i}_verts"], g[f"mesh{cow_i}_indices"])
-    quad = sb.add_mesh(*scenes.quad())
-    white = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.7, 0.7, 0.7)))
-    red = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.7, 0.3, 0.3)))
-    lamp = sb.add_material(abi.PTX_MAT_EMISSIVE, sb.add_constant_texture((1, 1, 1), 6.0))
-    for ix in range(n):
-        for iy in range(n):
-            for iz in range(n):
-                sb.add_instance(cow, white if (ix + iy + iz) % 2 else red,
-                                scenes.trs((ix * 1.2, iy * 1.2, iz * 1.2), axis=(0, 1, 0), deg=17.0 * (ix + 2 * iy + 3 * iz), scale=(0.9, 0.9, 0.9)))
-    L = n * 1.2
-    sb.add_instance(quad, white, scenes.trs((L / 2, -0.8, L / 2), scale=(L, 1, L)))
-    sb.add_instance(quad, lamp, scenes.trs((L / 2, L + 1.0, L / 2), axis=(1, 0, 0), deg=180, scale=(L / 2, 1, L / 2)))
-    cam = abi.PtxCamera()
-    cam.vertical_fov = 50.0
-    T = scenes.trs((L / 2, L * 0.7, L * 2.4), axis=(1, 0, 0), deg=-12)
-    for i in range(16):
-        cam.camera_to_world[i] = float(T[i])
-    return sb, cam
+    return scenes.instanced_cows(n)
 
 
 def cpu_render_baseline(sb, cam, w, h, spp, target_seconds=4.0):

@@ -1,7 +1,11 @@
 """Small seeded scenes shared by the CPU and GPU parity tests (inputs only, no expectations)."""
+import os
+
 import numpy as np
 
 from pathtracer_amd import abi, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def rotation(axis, deg):
@@ -104,3 +108,36 @@ def scene_rays(n, seed=7, extent=2.2, inside=True):
     r["d"] = synth._unit_f32(d)
     r["tmin"], r["tmax"] = 0.0, np.inf
     return r
+
+
+def cow_mesh():
+    """(verts, indices) of the reference's cow (media/js3d/cow.js3d: 5,856 triangles, shared vertices, thin
+    triangles), taken from the committed scene descriptor of refract_cow_cbox.js3d."""
+    g = np.load(os.path.join(GOLDEN, "scene_refract_cow_cbox.npz"), allow_pickle=False)
+    cow_i = max(range(int(g["n_meshes"])), key=lambda i: len(g[f"mesh{i}_indices"]))
+    return g[f"mesh{cow_i}_verts"], g[f"mesh{cow_i}_indices"]
+
+
+def instanced_cows(n):
+    """n^3 rotated instances of the cow mesh on a grid (10.1 M instanced triangles at n = 12), Lambertian, over a
+    floor quad and under one emissive quad; returns (SceneBuilder, PtxCamera without film settings)."""
+    sb = abi.SceneBuilder()
+    cow = sb.add_mesh(*cow_mesh())
+    q = sb.add_mesh(*quad())
+    white = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.7, 0.7, 0.7)))
+    red = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.7, 0.3, 0.3)))
+    lamp = sb.add_material(abi.PTX_MAT_EMISSIVE, sb.add_constant_texture((1, 1, 1), 6.0))
+    for ix in range(n):
+        for iy in range(n):
+            for iz in range(n):
+                sb.add_instance(cow, white if (ix + iy + iz) % 2 else red,
+                                trs((ix * 1.2, iy * 1.2, iz * 1.2), axis=(0, 1, 0), deg=17.0 * (ix + 2 * iy + 3 * iz), scale=(0.9, 0.9, 0.9)))
+    L = n * 1.2
+    sb.add_instance(q, white, trs((L / 2, -0.8, L / 2), scale=(L, 1, L)))
+    sb.add_instance(q, lamp, trs((L / 2, L + 1.0, L / 2), axis=(1, 0, 0), deg=180, scale=(L / 2, 1, L / 2)))
+    cam = abi.PtxCamera()
+    cam.vertical_fov = 50.0
+    T = trs((L / 2, L * 0.7, L * 2.4), axis=(1, 0, 0), deg=-12)
+    for i in range(16):
+        cam.camera_to_world[i] = float(T[i])
+    return sb, cam

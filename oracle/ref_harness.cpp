@@ -18,7 +18,10 @@
 #include "pathtracer/instance.h"
 #include "pathtracer/list.h"
 #include "pathtracer/tri_mesh.h"
+#include "scene/delta_light.h"
 #include "scene/env_light.h"
+#include "pathtracer/samplers.h"
+#include "util/hdr_image.h"
 #include "scene/material.h"
 #include "scene/shape.h"
 #include "scene/texture.h"
@@ -331,6 +334,64 @@ void ref_env_sphere_evaluate(uint32_t w, uint32_t h, const float* pixels, int sa
 	for (uint32_t i = 0; i < n; i++) {
 		Spectrum s = map.evaluate(Vec3(dirs3[i * 3], dirs3[i * 3 + 1], dirs3[i * 3 + 2]));
 		out3[i * 3] = s.r, out3[i * 3 + 1] = s.g, out3[i * 3 + 2] = s.b;
+	}
+}
+
+// HDR_Image::tonemap_to (util/hdr_image.cpp:201-225): w*h RGB floats -> w*h RGBA bytes.
+void ref_tonemap(uint32_t w, uint32_t h, const float* rgb, float exposure, uint8_t* rgba) {
+	std::vector<Spectrum> px(size_t(w) * h);
+	for (size_t i = 0; i < px.size(); i++) px[i] = Spectrum(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
+	HDR_Image img(w, h, px);
+	std::vector<uint8_t> data;
+	img.tonemap_to(data, exposure);
+	std::memcpy(rgba, data.data(), data.size());
+}
+
+// Delta_Lights::{Point,Directional,Spot}::incoming (scene/delta_light.cpp:7-40) through PT::Light_Instance::incoming
+// (pathtracer/instance.h:74-91) with local_to_world T16 (null: identity).  out7 per point: radiance rgb, direction xyz, distance.
+void ref_delta_incoming(uint32_t type, const float* color3, float intensity, float inner, float outer, const float* T16, const float* pts3,
+                        uint32_t n, float* out7) {
+	Delta_Light light;
+	const Spectrum color(color3[0], color3[1], color3[2]);
+	if (type == PTX_LIGHT_POINT) {
+		Delta_Lights::Point l;
+		l.color = color, l.intensity = intensity;
+		light.light = l;
+	} else if (type == PTX_LIGHT_DIRECTIONAL) {
+		Delta_Lights::Directional l;
+		l.color = color, l.intensity = intensity;
+		light.light = l;
+	} else {
+		Delta_Lights::Spot l;
+		l.color = color, l.intensity = intensity, l.inner_angle = inner, l.outer_angle = outer;
+		light.light = l;
+	}
+	PT::Light_Instance inst(&light, T16 ? mat_from(T16) : Mat4::I);
+	for (uint32_t i = 0; i < n; i++) {
+		Delta_Lights::Incoming in = inst.incoming(Vec3(pts3[i * 3], pts3[i * 3 + 1], pts3[i * 3 + 2]));
+		float* o = out7 + size_t(i) * 7;
+		o[0] = in.radiance.r, o[1] = in.radiance.g, o[2] = in.radiance.b;
+		o[3] = in.direction.x, o[4] = in.direction.y, o[5] = in.direction.z, o[6] = in.distance;
+	}
+}
+
+// Samplers::Rect::sample / pdf (pathtracer/samplers.cpp:7-19): n samples from RNG(seed); out3 = x, y, pdf(sample).
+void ref_sampler_rect(uint32_t seed, float sx, float sy, uint32_t n, float* out3) {
+	RNG rng(seed);
+	Samplers::Rect r(Vec2(sx, sy));
+	for (uint32_t i = 0; i < n; i++) {
+		Vec2 v = r.sample(rng);
+		out3[i * 3] = v.x, out3[i * 3 + 1] = v.y, out3[i * 3 + 2] = r.pdf(v);
+	}
+}
+
+// Samplers::Hemisphere::Cosine::sample / pdf (pathtracer/samplers.cpp:67-83): out4 = direction xyz, pdf(direction).
+void ref_sampler_cosine(uint32_t seed, uint32_t n, float* out4) {
+	RNG rng(seed);
+	Samplers::Hemisphere::Cosine c;
+	for (uint32_t i = 0; i < n; i++) {
+		Vec3 d = c.sample(rng);
+		out4[i * 4] = d.x, out4[i * 4 + 1] = d.y, out4[i * 4 + 2] = d.z, out4[i * 4 + 3] = c.pdf(d);
 	}
 }
 

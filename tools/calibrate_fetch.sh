@@ -2,8 +2,8 @@
 # FETCH_SIZE against a known byte count in the traversal's access pattern: one random 64-byte record per
 # lane (four 16-byte loads) from a 1 GB table, far larger than the L2s.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/calib; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o p -- $R/scratch/bin/gather_bench 16000000 > $OUT/run.log 2>&1 || exit 1
-timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/l2 -o p -- $R/scratch/bin/gather_bench 16000000 > $OUT/run2.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o p -- $R/tools/bin/gather_bench 16000000 > $OUT/run.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/l2 -o p -- $R/tools/bin/gather_bench 16000000 > $OUT/run2.log 2>&1 || exit 1
 python3 - <<PY
 import sqlite3, glob
 for d in ("fetch", "l2"):

@@ -255,6 +255,12 @@ uint64_t ptx_noalloc_max_rays(void);
  * reports how many differ in any bit. */
 int ptx_trace_closest_stats(ptx_scene_t scene, const PtxRay* rays, uint64_t n, uint32_t* stats3, uint32_t flags);
 int ptx_selftest_division(int device, uint64_t pairs, uint64_t seed, uint64_t* mismatches);
+/* The render's random stream on the device (it replaces the reference's per-tile mt19937, util/rand.cpp:17-40).
+ * ptx_selftest_philox: n Philox-4x32-10 blocks, counters4[4*i..] and keys2[2*i..] -> out4[4*i..], for checking the
+ * generator against the published known-answer vectors.  ptx_selftest_path_units: the first n RNG::unit() values of
+ * the stream of (seed, pixel, sample) exactly as ptx_render_tiles consumes them. */
+int ptx_selftest_philox(int device, const uint32_t* counters4, const uint32_t* keys2, uint32_t n, uint32_t* out4);
+int ptx_selftest_path_units(int device, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
 
 /* ------------------------------------------------------------------ rendering */
 typedef struct PtxCamera {                   /* scene/camera.h:12-30 + Pathtracer::set_camera (pathtracer.cpp:389-396) */
@@ -293,6 +299,14 @@ int64_t* ptx_frame_accum(ptx_frame_t frame);      /* device pointer, int64[3*wid
 uint32_t* ptx_frame_samples(ptx_frame_t frame);   /* device pointer, uint32[width*height] */
 int ptx_frame_upload(ptx_frame_t frame, const int64_t* accum_rgb, const uint32_t* samples);
 int ptx_frame_download(ptx_frame_t frame, int64_t* accum_rgb, uint32_t* samples);
+int ptx_frame_clear(ptx_frame_t frame);
+/* The reference's tiles run on a thread pool and every finished tile is added into ONE accumulator under a mutex
+ * (pathtracer.cpp:566-584, 407-427).  With several GPUs every GPU accumulates the tiles it was dealt in a film of its
+ * own (ptx_frame_create on that GPU's scene); ptx_frame_reduce then adds every part into `dst` (dst += sum of parts,
+ * parts unchanged): integer sums of 40.24 fixed-point values and of the sample counts, so the frame is the one a single
+ * accumulator would hold, whatever the order (pathtracer.h:80-83).  Parts on another GPU than dst's are brought over
+ * with one peer copy each (xGMI where the GPUs are linked).  No work may be in flight on the parts while it runs. */
+int ptx_frame_reduce(ptx_frame_t dst, const ptx_frame_t* parts, uint32_t n_parts);
 void ptx_frame_destroy(ptx_frame_t frame);
 
 /* Pathtracer::render's tile list (pathtracer.cpp:522-563): 100x100-pixel x 50-sample tiles,

@@ -417,4 +417,58 @@ void orc_camera_ray(const PtxCamera* cam, uint32_t px, uint32_t py, float a, flo
 	out->tmin = ray.dist_bounds.x, out->tmax = ray.dist_bounds.y;
 }
 
+// Light_Instance::incoming (pathtracer/instance.h:74-91) over Delta_Lights::*::incoming (scene/delta_light.cpp:7-40).
+// out7 per point: radiance rgb, direction xyz, distance.  T16 null: identity.
+void orc_delta_incoming(uint32_t type, const float* color3, float intensity, float inner, float outer, const float* T16, const float* pts3,
+                        uint32_t n, float* out7) {
+	DeltaLight l;
+	l.type = int(type), l.color = {color3[0], color3[1], color3[2]}, l.intensity = intensity, l.inner_angle = inner, l.outer_angle = outer;
+	if (T16) l.set(mat_from(T16));
+	for (uint32_t i = 0; i < n; i++) {
+		DeltaLight::Incoming in = l.incoming(V3{pts3[i * 3], pts3[i * 3 + 1], pts3[i * 3 + 2]});
+		float* o = out7 + size_t(i) * 7;
+		o[0] = in.radiance.x, o[1] = in.radiance.y, o[2] = in.radiance.z;
+		o[3] = in.direction.x, o[4] = in.direction.y, o[5] = in.direction.z, o[6] = in.distance;
+	}
+}
+
+// Samplers::Rect::sample / pdf (pathtracer/samplers.cpp:7-19) as g++ compiles it: the two draws are arguments of
+// one constructor call and g++ evaluates them right to left, so the first draw scales y.  out3 = x, y, pdf.
+void orc_sampler_rect(uint32_t seed, float sx, float sy, uint32_t n, float* out3) {
+	RNG rng(seed);
+	for (uint32_t i = 0; i < n; i++) {
+		const float first = rng.unit(), second = rng.unit();
+		const float x = second * sx, y = first * sy;
+		const bool outside = x < 0.0f || x > sx || y < 0.0f || y > sy;
+		out3[i * 3] = x, out3[i * 3 + 1] = y, out3[i * 3 + 2] = outside ? 0.0f : 1.0f / (sx * sy);
+	}
+}
+
+// n consecutive Camera::sample_ray calls (scene/camera.cpp:7-48) through pixel (px, py) on one mt19937(seed) stream, in
+// the reference's (g++) draw order, each followed by ray.transform(camera_to_world) as do_trace does (pathtracer.cpp:453-454).
+void orc_camera_sample_rays(const PtxCamera* cam, uint32_t seed, uint32_t px, uint32_t py, uint32_t n, PtxRay* out) {
+	Camera c;
+	c.vertical_fov = cam->vertical_fov, c.aspect_ratio = cam->aspect_ratio, c.film_w = cam->film_width, c.film_h = cam->film_height;
+	c.film_max_ray_depth = cam->film_max_ray_depth;
+	c.camera_to_world = mat_from(cam->camera_to_world);
+	RNG rng(seed);
+	for (uint32_t i = 0; i < n; i++) {
+		Ray ray = c.sample_ray(rng, px, py, true).first;
+		ray.transform(c.camera_to_world);
+		out[i] = PtxRay{{ray.point.x, ray.point.y, ray.point.z}, {ray.dir.x, ray.dir.y, ray.dir.z}, ray.dist_bounds.x, ray.dist_bounds.y};
+	}
+}
+
+// Samplers::Hemisphere::Cosine::sample / pdf (pathtracer/samplers.cpp:67-83): out4 = direction xyz, pdf.
+void orc_sampler_cosine(uint32_t seed, uint32_t n, float* out4) {
+	RNG rng(seed);
+	for (uint32_t i = 0; i < n; i++) {
+		V3 d = cosine_hemisphere_sample(rng);
+		out4[i * 4] = d.x, out4[i * 4 + 1] = d.y, out4[i * 4 + 2] = d.z, out4[i * 4 + 3] = cosine_hemisphere_pdf(d);
+	}
+}
+
+// One Philox-4x32-10 block: counter c[4], key k[2] -> out[4] (known-answer checks).
+void orc_philox_block(const uint32_t* c4, const uint32_t* k2, uint32_t* out4) { Philox::block(c4[0], c4[1], c4[2], c4[3], k2[0], k2[1], out4); }
+
 }  // extern "C"

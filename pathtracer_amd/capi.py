@@ -67,6 +67,8 @@ def lib():
     L.ptx_trace_any.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32]
     L.ptx_trace_closest_stats.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32]
     L.ptx_selftest_division.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.ptx_selftest_philox.argtypes = [C.c_int, vp, vp, C.c_uint32, vp]
+    L.ptx_selftest_path_units.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.ptx_render_tiles.argtypes = [vp, C.POINTER(abi.PtxCamera), vp, C.c_uint32, C.c_uint64, vp, vp, C.c_uint32]
     L.ptx_make_tiles.restype = C.c_uint32
     L.ptx_make_tiles.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32]
@@ -330,6 +332,21 @@ def selftest_division(pairs, seed=1, device=0):
     bad = C.c_uint64()
     check(lib().ptx_selftest_division(device, pairs, seed, C.byref(bad)))
     return bad.value
+
+
+def selftest_philox(counters, keys, device=0):
+    """Philox-4x32-10 blocks computed on the device: counters (n x 4 uint32), keys (n x 2 uint32) -> n x 4 uint32."""
+    counters = np.ascontiguousarray(counters, dtype=np.uint32).reshape(-1, 4)
+    keys = np.ascontiguousarray(keys, dtype=np.uint32).reshape(-1, 2)
+    out = np.zeros_like(counters)
+    check(lib().ptx_selftest_philox(device, counters.ctypes.data, keys.ctypes.data, len(counters), out.ctypes.data))
+    return out
+
+
+def selftest_path_units(seed, pixel, sample, n, device=0):
+    out = np.zeros(n, dtype=np.float32)
+    check(lib().ptx_selftest_path_units(device, seed, pixel, sample, n, out.ctypes.data))
+    return out
 
 
 def make_tiles(w, h, samples, fixed_seed):

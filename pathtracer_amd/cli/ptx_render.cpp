@@ -1,7 +1,8 @@
 // ptx_render -- headless renderer with the reference's command line (main.cpp:50-75, 96-358):
 //   -s,--scene FILE  -c,--camera NAME  -o,--output FILE.png  --trace  --no_bvh  --exposure F  --seed N
 //   --film-width N  --film-height N  --film-samples N  --film-max-ray-depth N
-// plus  --device N  and  --fresnel gcc|float  (which behaviour of Materials::schlick to reproduce,
+// plus  --device N  (one GPU),  --devices N  (GPUs 0..N-1: tiles dealt across them, films added at the end;
+// --devices a,b,c names them)  and  --fresnel gcc|float  (which behaviour of Materials::schlick to reproduce,
 // scene/material.cpp:58-71).  Exit codes follow the reference: 0 on success, 1 on any reported error.
 #include <chrono>
 #include <cmath>
@@ -18,7 +19,7 @@
 
 static void usage() {
 	std::cerr << "usage: ptx_render --trace -s scene.js3d -c camera_instance [-o out.png] [--no_bvh] [--exposure f] [--seed n]\n"
-	             "                  [--film-width n] [--film-height n] [--film-samples n] [--film-max-ray-depth n] [--device n] [--fresnel gcc|float]\n";
+	             "                  [--film-width n] [--film-height n] [--film-samples n] [--film-max-ray-depth n] [--device n | --devices n | --devices a,b,..] [--fresnel gcc|float]\n";
 }
 
 int main(int argc, char** argv) {
@@ -26,7 +27,7 @@ int main(int argc, char** argv) {
 	bool pathtrace = false, no_bvh = false;
 	float exposure = 1.0f;
 	uint32_t seed = 0, film_width = -1U, film_height = -1U, film_samples = -1U, film_max_ray_depth = -1U;
-	int device = 0;
+	std::vector<int> devices{0};
 	for (int i = 1; i < argc; i++) {
 		const std::string a = argv[i];
 		auto value = [&]() -> const char* {
@@ -47,7 +48,24 @@ int main(int argc, char** argv) {
 		else if (a == "--film-height") film_height = uint32_t(std::strtoul(value(), nullptr, 0));
 		else if (a == "--film-samples") film_samples = uint32_t(std::strtoul(value(), nullptr, 0));
 		else if (a == "--film-max-ray-depth") film_max_ray_depth = uint32_t(std::strtoul(value(), nullptr, 0));
-		else if (a == "--device") device = std::atoi(value());
+		else if (a == "--device") devices = {std::atoi(value())};
+		else if (a == "--devices") {
+			const std::string v = value();
+			devices.clear();
+			if (v.find(',') == std::string::npos) {
+				for (int d = 0; d < std::atoi(v.c_str()); d++) devices.push_back(d);
+			} else {
+				for (size_t pos = 0; pos <= v.size();) {
+					const size_t end = std::min(v.find(',', pos), v.size());
+					devices.push_back(std::atoi(v.substr(pos, end - pos).c_str()));
+					pos = end + 1;
+				}
+			}
+			if (devices.empty()) {
+				std::cerr << "ERROR: --devices needs a count of at least 1 or a list." << std::endl;
+				return 1;
+			}
+		}
 		else if (a == "--fresnel") fresnel = value();
 		else if (a == "-h" || a == "--help") {
 			usage();
@@ -103,8 +121,10 @@ int main(int argc, char** argv) {
 	if (seed == 0) seed = (std::random_device())();   // main.cpp:186-188
 	ptx_js3d_set_modes(js, no_bvh ? 0 : 1, fresnel == "float" ? PTX_FRESNEL_FLOAT_ABS : PTX_FRESNEL_GCC_INT_ABS);
 
-	std::printf("Render settings:\n\twidth: %u\n\theight: %u\n\texposure: %f\n\tseed: 0x%X\n\tsamples: %u\n\tmax depth: %u\n\tdevice: %d\n", cam.film_width,
-	            cam.film_height, exposure, seed, cam.film_samples, cam.film_max_ray_depth, device);
+	std::printf("Render settings:\n\twidth: %u\n\theight: %u\n\texposure: %f\n\tseed: 0x%X\n\tsamples: %u\n\tmax depth: %u\n\tdevices:", cam.film_width,
+	            cam.film_height, exposure, seed, cam.film_samples, cam.film_max_ray_depth);
+	for (int d : devices) std::printf(" %d", d);
+	std::printf("\n");
 	if (no_bvh) std::printf("\tusing object list instead of BVH\n");
 	std::printf("\tpathtracing...\n");
 
@@ -115,7 +135,7 @@ int main(int argc, char** argv) {
 	int status = 0;
 	try {
 		PT::Pathtracer pathtracer;
-		pathtracer.set_device(device);
+		pathtracer.set_devices(devices);
 		pathtracer.set_seed(seed);
 		pathtracer.use_bvh(!no_bvh);
 		pathtracer.render(*ptx_js3d_scene_desc(js), cam,

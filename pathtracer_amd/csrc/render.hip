@@ -402,6 +402,23 @@ __global__ void __launch_bounds__(256) k_flush(RenderBuffers rb, uint32_t n_slot
 	atomicAdd(&samples[si.pixel], si.s_count);
 }
 
+// Known-answer access to the random stream: one Philox block per thread.
+__global__ void k_philox_blocks(const uint32_t* __restrict__ counters, const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ out) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint32_t r[4];
+	philox4x32_10(counters[4 * i], counters[4 * i + 1], counters[4 * i + 2], counters[4 * i + 3], keys[2 * i], keys[2 * i + 1], r);
+	out[4 * i] = r[0], out[4 * i + 1] = r[1], out[4 * i + 2] = r[2], out[4 * i + 3] = r[3];
+}
+
+// The first `n` unit draws of the path stream (seed, pixel, sample), as k_raygen / k_shade consume them.
+__global__ void k_path_units(uint32_t key0, uint32_t key1, uint32_t pixel, uint32_t sample, uint32_t n, float* __restrict__ out) {
+	if (blockIdx.x || threadIdx.x) return;
+	PathRng rng;
+	rng.start(key0, key1, pixel, sample, 0);
+	for (uint32_t i = 0; i < n; i++) out[i] = rng.next_unit();
+}
+
 static int device_alloc(PtxScene* s, int slot, size_t bytes, void** out) {
 	if (s->scratch_bytes[slot] < bytes) {
 		if (s->scratch[slot]) PTX_HIP(hipFree(s->scratch[slot]));
@@ -532,6 +549,42 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 	return PTX_OK;
 }
 
+extern "C" int ptx_selftest_philox(int device, const uint32_t* counters4, const uint32_t* keys2, uint32_t n, uint32_t* out4) {
+	if (n && (!counters4 || !keys2 || !out4)) return fail(PTX_ERR_INVALID, "ptx_selftest_philox: null argument");
+	if (n == 0) return PTX_OK;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(PTX_ERR_NO_DEVICE, "device index out of range");
+	PTX_HIP(hipSetDevice(device));
+	uint32_t* d = nullptr;
+	PTX_HIP(hipMalloc(&d, size_t(n) * 10 * sizeof(uint32_t)));
+	hipError_t e = hipMemcpy(d, counters4, size_t(n) * 16, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(d + 4 * size_t(n), keys2, size_t(n) * 8, hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_philox_blocks, dim3((n + 255) / 256), dim3(256), 0, nullptr, d, d + 4 * size_t(n), n, d + 6 * size_t(n));
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpy(out4, d + 6 * size_t(n), size_t(n) * 16, hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return hip_fail(e, "ptx_selftest_philox");
+	return PTX_OK;
+}
+
+extern "C" int ptx_selftest_path_units(int device, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out) {
+	if (n && !out) return fail(PTX_ERR_INVALID, "ptx_selftest_path_units: null argument");
+	if (n == 0) return PTX_OK;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(PTX_ERR_NO_DEVICE, "device index out of range");
+	PTX_HIP(hipSetDevice(device));
+	float* d = nullptr;
+	PTX_HIP(hipMalloc(&d, size_t(n) * sizeof(float)));
+	hipLaunchKernelGGL(k_path_units, dim3(1), dim3(64), 0, nullptr, uint32_t(seed), uint32_t(seed >> 32), pixel, sample, n, d);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpy(out, d, size_t(n) * sizeof(float), hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return hip_fail(e, "ptx_selftest_path_units");
+	return PTX_OK;
+}
+
 // ------------------------------------------------------------------ device-resident film
 struct PtxFrame {
 	PtxScene* scene;
@@ -578,6 +631,64 @@ extern "C" int ptx_frame_download(ptx_frame_t f, int64_t* accum_rgb, uint32_t* s
 	PTX_HIP(hipStreamSynchronize(f->scene->stream));
 	return PTX_OK;
 }
+extern "C" int ptx_frame_clear(ptx_frame_t f) {
+	if (!f) return fail(PTX_ERR_INVALID, "ptx_frame_clear: null frame");
+	PTX_HIP(hipSetDevice(f->scene->device));
+	PTX_HIP(hipMemsetAsync(f->accum, 0, f->n_pixels * (3 * sizeof(int64_t) + sizeof(uint32_t)), f->scene->stream));
+	PTX_HIP(hipStreamSynchronize(f->scene->stream));
+	return PTX_OK;
+}
+
+namespace ptx {
+// dst += src for one film: 3 int64 sums and one sample count per pixel (integer adds: any order gives the same frame).
+__global__ void __launch_bounds__(256) k_frame_add(unsigned long long* __restrict__ dst_acc, const unsigned long long* __restrict__ src_acc,
+                                                   uint32_t* __restrict__ dst_smp, const uint32_t* __restrict__ src_smp, size_t n_pixels) {
+	const size_t stride = size_t(gridDim.x) * blockDim.x;
+	for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_pixels * 3; i += stride) dst_acc[i] += src_acc[i];
+	for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_pixels; i += stride) dst_smp[i] += src_smp[i];
+}
+}  // namespace ptx
+
+extern "C" int ptx_frame_reduce(ptx_frame_t dst, const ptx_frame_t* parts, uint32_t n_parts) {
+	if (!dst || (n_parts && !parts)) return fail(PTX_ERR_INVALID, "ptx_frame_reduce: null argument");
+	for (uint32_t i = 0; i < n_parts; i++) {
+		if (!parts[i] || parts[i] == dst) return fail(PTX_ERR_INVALID, "ptx_frame_reduce: a part is null or is the destination itself");
+		if (parts[i]->n_pixels != dst->n_pixels) return fail(PTX_ERR_INVALID, "ptx_frame_reduce: films of different sizes");
+	}
+	if (n_parts == 0) return PTX_OK;
+	const int dev = dst->scene->device;
+	hipStream_t stream = dst->scene->stream;
+	PTX_HIP(hipSetDevice(dev));
+	const size_t bytes = dst->n_pixels * (3 * sizeof(int64_t) + sizeof(uint32_t));
+	const size_t a_bytes = dst->n_pixels * 3 * sizeof(int64_t);
+	void* staging = nullptr;   // one film's worth on the destination GPU, for parts that live on another GPU
+	const dim3 block(256), grid(uint32_t(std::min<size_t>((dst->n_pixels * 3 + 255) / 256, 256 * 64)));
+	int rc = PTX_OK;
+	for (uint32_t i = 0; i < n_parts && rc == PTX_OK; i++) {
+		const PtxFrame* p = parts[i];
+		const unsigned long long* src_acc = reinterpret_cast<const unsigned long long*>(p->accum);
+		const uint32_t* src_smp = p->samples;
+		hipError_t e = hipSuccess;
+		if (p->scene->device != dev) {
+			// the film is one allocation (sums, then counts): one copy over xGMI (or through the host where the
+			// two GPUs have no direct path -- hipMemcpyPeer takes care of either)
+			if (!staging) e = hipMalloc(&staging, bytes);
+			if (e == hipSuccess) e = hipMemcpyPeerAsync(staging, dev, p->accum, p->scene->device, bytes, stream);
+			src_acc = static_cast<const unsigned long long*>(staging);
+			src_smp = reinterpret_cast<const uint32_t*>(static_cast<const char*>(staging) + a_bytes);
+		}
+		if (e == hipSuccess) {
+			hipLaunchKernelGGL(k_frame_add, grid, block, 0, stream, reinterpret_cast<unsigned long long*>(dst->accum), src_acc, dst->samples, src_smp, dst->n_pixels);
+			e = hipGetLastError();
+		}
+		if (e == hipSuccess && staging) e = hipStreamSynchronize(stream);   // the staging film is reused by the next part
+		if (e != hipSuccess) rc = hip_fail(e, "ptx_frame_reduce");
+	}
+	if (rc == PTX_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(PTX_ERR_DEVICE, "ptx_frame_reduce: synchronising the destination's stream failed");
+	if (staging) (void)hipFree(staging);
+	return rc;
+}
+
 extern "C" void ptx_frame_destroy(ptx_frame_t f) {
 	if (!f) return;
 	(void)hipSetDevice(f->scene->device);

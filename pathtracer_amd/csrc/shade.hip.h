@@ -35,21 +35,23 @@ __device__ __forceinline__ bool finite3(V3f a) { return isfinite(a.x) && isfinit
 
 // ---- random numbers: Philox-4x32-10, key = render seed, counter = (block, pixel, sample, 0).
 // Draw i of a path is word i%4 of block i/4; RNG::unit() = scalbn(float(u32), -32) (rand.cpp:17-21).
+// One Philox-4x32-10 block (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): counter c, key k.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+	for (int i = 0; i < 10; i++) {
+		const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+		const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+		const uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+		c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+		k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+	}
+	out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
 struct PathRng {
 	uint32_t key0, key1, pixel, sample, draws;
 	uint32_t buf[4];
-	__device__ __forceinline__ void refill() {
-		uint32_t c0 = draws >> 2, c1 = pixel, c2 = sample, c3 = 0, k0 = key0, k1 = key1;
-#pragma unroll
-		for (int i = 0; i < 10; i++) {
-			const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-			const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-			const uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
-			c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-			k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
-		}
-		buf[0] = c0, buf[1] = c1, buf[2] = c2, buf[3] = c3;
-	}
+	__device__ __forceinline__ void refill() { philox4x32_10(draws >> 2, pixel, sample, 0u, key0, key1, buf); }
 	__device__ __forceinline__ void start(uint32_t k0, uint32_t k1, uint32_t px, uint32_t s, uint32_t d) {
 		key0 = k0, key1 = k1, pixel = px, sample = s, draws = d;
 		if (d & 3u) refill();   // resume in the middle of a block

@@ -19,6 +19,9 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <mutex>
+#include <random>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -188,10 +191,11 @@ public:
 			const Triangle& tri = triangle_bvh.primitives[hits[i].prim];
 			const Tri_Mesh_Vert &a = verts[tri.v0], &b = verts[tri.v1], &c = verts[tri.v2];
 			const float u = bary[2 * i], v = bary[2 * i + 1], w = 1 - u - v;   // tri_mesh.cpp:97-101
-			// position = ray.point + dir * t (tri_mesh.cpp:91-97); the ABI returns distance = |dir * t|, which for
-			// the unit directions Ray's constructor makes equals t to rounding
+			// position = ray.point + dir * t (tri_mesh.cpp:91-97).  The ABI returns distance = |dir * t|, not t: t is
+			// recomputed here for the winning triangle with Triangle::hit's own expression (tri_mesh.cpp:58-85).
 			const Vec3 o = rays[i].point, dd = rays[i].dir;
-			t.position = Vec3{o.x + dd.x * t.distance, o.y + dd.y * t.distance, o.z + dd.z * t.distance};
+			const float tt = triangle_t(a.position, b.position, c.position, o, dd);
+			t.position = Vec3{o.x + dd.x * tt, o.y + dd.y * tt, o.z + dd.z * tt};
 			t.normal = Vec3{w * a.normal.x + u * b.normal.x + v * c.normal.x, w * a.normal.y + u * b.normal.y + v * c.normal.y, w * a.normal.z + u * b.normal.z + v * c.normal.z};
 			t.uv = Vec2{w * a.uv.x + u * b.uv.x + v * c.uv.x, w * a.uv.y + u * b.uv.y + v * c.uv.y};
 		}
@@ -200,6 +204,15 @@ public:
 	Trace hit(const Ray& ray) const { return hit_batch(std::vector<Ray>{ray}, false)[0]; }
 
 private:
+	static Vec3 sub(Vec3 l, Vec3 r) { return Vec3{l.x - r.x, l.y - r.y, l.z - r.z}; }
+	static Vec3 cross(Vec3 l, Vec3 r) { return Vec3{l.y * r.z - l.z * r.y, l.z * r.x - l.x * r.z, l.x * r.y - l.y * r.x}; }
+	static float dot(Vec3 l, Vec3 r) { return l.x * r.x + l.y * r.y + l.z * r.z; }
+	// the `t` of Triangle::hit: third component of Vec3(-dot(cross(s,e2),dir), dot(cross(e1,dir),s), -dot(cross(s,e2),e1)) / denom
+	static float triangle_t(Vec3 v0, Vec3 v1, Vec3 v2, Vec3 o, Vec3 dir) {
+		const Vec3 s = sub(o, v0), e1 = sub(v1, v0), e2 = sub(v2, v0);
+		const float denom = dot(cross(e1, dir), e2);
+		return -dot(cross(s, e2), e1) / denom;
+	}
 	void release() {
 		if (scene) ptx_scene_destroy(scene);
 		scene = nullptr;
@@ -226,76 +239,81 @@ public:
 	Pathtracer() = default;
 	~Pathtracer() {
 		cancel();
-		if (scene) ptx_scene_destroy(scene);
+		destroy_scenes();
 	}
 	Pathtracer(const Pathtracer&) = delete;
 	Pathtracer& operator=(const Pathtracer&) = delete;
 
 	void use_bvh(bool use) { scene_use_bvh = use; }   // pathtracer.h:37
-	void set_device(int d) { device = d; }
-	void set_seed(uint32_t fixed_seed) { seed = fixed_seed; }   // RNG::fixed_seed (util/rand.cpp), main.cpp:66
+	// The GPUs the render runs on.  With more than one entry every GPU holds a copy of the scene, takes every
+	// n-th tile of the reference's centre-out tile order into a film of its own on a host thread of its own, and
+	// the films are added at the end (ptx_frame_reduce): what the reference's thread pool does with its tiles and
+	// its one mutex-guarded accumulator (pathtracer.cpp:566-584).  The same GPU may be listed twice.
+	void set_devices(const std::vector<int>& list) {
+		cancel();
+		destroy_scenes();
+		devices = list.empty() ? std::vector<int>{0} : list;
+	}
+	void set_device(int d) { set_devices({d}); }
+	// RNG::fixed_seed (util/rand.cpp, main.cpp:66).  0 = none: every render() call draws a seed of its own, as the
+	// reference's unseeded RNG does (pathtracer.cpp:533-534).
+	void set_seed(uint32_t fixed_seed) { seed = fixed_seed; }
 	void set_tiles_per_batch(uint32_t n) { tiles_per_batch = n ? n : 1; }
 	void set_report_interval(float seconds) { report_interval = seconds; }   // 0: a report (and a film read-back) after every batch
 
-	// build_scene(Scene&) (pathtracer.cpp:182-387) from the flattened descriptor
+	// build_scene(Scene&) (pathtracer.cpp:182-387) from the flattened descriptor, once per GPU
 	void build_scene(const PtxSceneDesc& in) {
 		const auto t0 = std::chrono::steady_clock::now();
-		if (scene) ptx_scene_destroy(scene);
-		scene = nullptr;
+		destroy_scenes();
 		PtxSceneDesc d = in;
 		std::vector<PtxMeshDesc> meshes(d.meshes, d.meshes + d.n_meshes);
 		for (auto& m : meshes) m.use_bvh = scene_use_bvh ? 1 : 0;
 		d.meshes = meshes.data(), d.use_bvh = scene_use_bvh ? 1 : 0;
-		check(ptx_scene_create(device, &d, &scene));
+		scenes.assign(devices.size(), nullptr);
+		std::vector<std::string> errors(devices.size());
+		std::vector<std::thread> th;
+		for (size_t k = 0; k < devices.size(); k++)
+			th.emplace_back([&, k] {
+				if (ptx_scene_create(devices[k], &d, &scenes[k]) != PTX_OK) errors[k] = ptx_last_error();   // the error text is per thread
+			});
+		for (auto& t : th) t.join();
+		for (const std::string& e : errors)
+			if (!e.empty()) {
+				destroy_scenes();
+				throw Error(e);
+			}
 		build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
 	}
 	void set_camera(const PtxCamera& c) { camera = c; }
 
-	// render(scene, camera, callback, quit, add_samples) (pathtracer.cpp:491-584): asynchronous; the
-	// callback receives (fraction done, image so far) from the render thread after every batch of tiles.
+	// render(scene, camera, callback, quit, add_samples) (pathtracer.cpp:491-584): asynchronous; the callback
+	// receives (fraction done, image so far) from a render thread after batches of tiles.
+	// add_samples keeps the film and the scene built by the previous call when the film size is unchanged
+	// (pathtracer.cpp:504-519) and adds film_samples NEW samples per pixel: the random streams are named by
+	// (seed, pixel, sample index), so the pass continues the sample index where the film's count stands.  (With a
+	// fixed seed the reference re-seeds its tile-seed generator and adds the same samples a second time; with no
+	// fixed seed it draws fresh ones.  Continuing the index gives fresh samples in both cases.)
 	void render(const PtxSceneDesc& scene_desc, const PtxCamera& cam, std::function<void(Render_Report&&)>&& f, bool* quit, bool add_samples = false) {
 		cancel();
-		build_scene(scene_desc);
-		set_camera(cam);
 		const size_t npix = size_t(cam.film_width) * cam.film_height;
-		if (!add_samples || accumulator.size() != npix * 3) {
+		if (accumulator_samples.size() != npix || accumulator_w != cam.film_width || scenes.empty()) add_samples = false;   // pathtracer.cpp:504-506
+		set_camera(cam);
+		if (!add_samples) {
+			build_scene(scene_desc);
+			accumulator_w = cam.film_width;
 			accumulator.assign(npix * 3, 0);
 			accumulator_samples.assign(npix, 0);
+			render_seed = seed ? seed : std::random_device{}();
 		}
-		tiles.resize(ptx_make_tiles(cam.film_width, cam.film_height, cam.film_samples, seed, nullptr, 0));
-		ptx_make_tiles(cam.film_width, cam.film_height, cam.film_samples, seed, tiles.data(), uint32_t(tiles.size()));
+		const uint32_t s_done = samples_per_pixel_max();   // the pass continues the sample index from here
+		tiles.resize(ptx_make_tiles(cam.film_width, cam.film_height, cam.film_samples, render_seed, nullptr, 0));
+		ptx_make_tiles(cam.film_width, cam.film_height, cam.film_samples, render_seed, tiles.data(), uint32_t(tiles.size()));
+		for (PtxTile& t : tiles) t.s_begin += s_done, t.s_end += s_done;
 		total_tiles = uint32_t(tiles.size()), traced_tiles = 0;
 		cancel_flag = quit, report_fn = std::move(f), failed.clear();
 		running = true;
 		render_start = std::chrono::steady_clock::now();
-		worker = std::thread([this] {
-			// The film stays on the GPU for the whole render; it comes back for a progress report (at most
-			// one per report interval) and when the render ends or is cancelled.
-			ptx_frame_t frame = nullptr;
-			bool ok = ptx_frame_create(scene, camera.film_width, camera.film_height, &frame) == PTX_OK &&
-			          ptx_frame_upload(frame, accumulator.data(), accumulator_samples.data()) == PTX_OK;
-			auto last_report = std::chrono::steady_clock::now();
-			for (uint32_t begin = 0; ok && begin < total_tiles; begin += tiles_per_batch) {
-				if ((cancel_flag && *cancel_flag) || stop) break;
-				const uint32_t n = std::min(tiles_per_batch, total_tiles - begin);
-				ok = ptx_render_tiles(scene, &camera, tiles.data() + begin, n, seed, ptx_frame_accum(frame), ptx_frame_samples(frame), PTX_MEM_DEVICE) == PTX_OK;
-				if (!ok) break;
-				traced_tiles += n;
-				const auto now = std::chrono::steady_clock::now();
-				const bool last = begin + n >= total_tiles;
-				if (report_fn && (last || std::chrono::duration<float>(now - last_report).count() >= report_interval)) {
-					ok = ptx_frame_download(frame, accumulator.data(), accumulator_samples.data()) == PTX_OK;
-					if (!ok) break;
-					report_fn(Render_Report{float(traced_tiles) / float(total_tiles), accumulator_to_image()});
-					last_report = now;
-				}
-			}
-			if (ok && frame) ok = ptx_frame_download(frame, accumulator.data(), accumulator_samples.data()) == PTX_OK;
-			if (!ok) failed = ptx_last_error();
-			ptx_frame_destroy(frame);
-			render_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - render_start).count();
-			running = false;
-		});
+		worker = std::thread([this] { run(); });
 	}
 	bool in_progress() const { return running; }   // pathtracer.cpp:479-481
 	std::pair<float, float> completion_time() const { return {build_seconds, render_seconds}; }   // pathtracer.cpp:483-485
@@ -310,6 +328,7 @@ public:
 	}
 	uint32_t samples_per_pixel_min() const { return accumulator_samples.empty() ? 0u : *std::min_element(accumulator_samples.begin(), accumulator_samples.end()); }
 	uint32_t samples_per_pixel_max() const { return accumulator_samples.empty() ? 0u : *std::max_element(accumulator_samples.begin(), accumulator_samples.end()); }
+	const std::vector<int64_t>& accumulator_rgb() const { return accumulator; }   // 40.24 fixed point, 3 per pixel
 	HDR_Image accumulator_to_image() const {   // pathtracer.cpp:429-442
 		HDR_Image img;
 		img.w = camera.film_width, img.h = camera.film_height;
@@ -319,14 +338,101 @@ public:
 	}
 
 private:
+	void destroy_scenes() {
+		for (ptx_scene_t s : scenes)
+			if (s) ptx_scene_destroy(s);
+		scenes.clear();
+	}
+
+	// The render thread.  Film layout: `total` on the first GPU holds what the film held before this pass (uploaded
+	// once); every GPU, the first included, adds its tiles into a zeroed film of its own (`parts`); a report or the
+	// end of the render computes total + sum of parts into `shown` and reads that back.  The films stay on the GPUs
+	// in between.  Workers render under a shared lock, the reduce takes it exclusively: no part has work in flight
+	// while it is read.
+	void run() {
+		const size_t n_dev = scenes.size();
+		std::vector<ptx_frame_t> parts(n_dev, nullptr);
+		ptx_frame_t total = nullptr, shown = nullptr;
+		std::string first_error;
+		std::mutex error_mutex;
+		auto note_error = [&] {
+			std::lock_guard<std::mutex> g(error_mutex);
+			if (first_error.empty()) first_error = ptx_last_error();
+		};
+		bool ok = ptx_frame_create(scenes[0], camera.film_width, camera.film_height, &total) == PTX_OK &&
+		          ptx_frame_create(scenes[0], camera.film_width, camera.film_height, &shown) == PTX_OK &&
+		          ptx_frame_upload(total, accumulator.data(), accumulator_samples.data()) == PTX_OK;
+		for (size_t k = 0; ok && k < n_dev; k++) ok = ptx_frame_create(scenes[k], camera.film_width, camera.film_height, &parts[k]) == PTX_OK;
+		if (!ok) note_error();
+		std::shared_mutex films;
+		std::atomic<bool> abort_all{!ok};
+		auto read_back = [&]() -> bool {   // caller holds `films` exclusively
+			const ptx_frame_t base[1] = {total};
+			return ptx_frame_clear(shown) == PTX_OK && ptx_frame_reduce(shown, base, 1) == PTX_OK && ptx_frame_reduce(shown, parts.data(), uint32_t(n_dev)) == PTX_OK &&
+			       ptx_frame_download(shown, accumulator.data(), accumulator_samples.data()) == PTX_OK;
+		};
+		auto last_report = std::chrono::steady_clock::now();
+		std::mutex report_mutex;
+		auto device_loop = [&](size_t k) {
+			// tiles k, k + n_dev, ... of the centre-out order (neighbouring tiles cost about the same), in batches
+			std::vector<PtxTile> mine;
+			for (size_t i = k; i < tiles.size(); i += n_dev) mine.push_back(tiles[i]);
+			for (size_t begin = 0; begin < mine.size() && !abort_all; begin += tiles_per_batch) {
+				if ((cancel_flag && *cancel_flag) || stop) break;
+				const uint32_t n = uint32_t(std::min<size_t>(tiles_per_batch, mine.size() - begin));
+				{
+					std::shared_lock<std::shared_mutex> lock(films);
+					if (ptx_render_tiles(scenes[k], &camera, mine.data() + begin, n, render_seed, ptx_frame_accum(parts[k]), ptx_frame_samples(parts[k]), PTX_MEM_DEVICE) != PTX_OK) {
+						note_error();
+						abort_all = true;
+						break;
+					}
+				}
+				const uint32_t done = traced_tiles.fetch_add(n) + n;
+				if (!report_fn) continue;
+				std::unique_lock<std::mutex> rl(report_mutex, std::try_to_lock);   // one reporter at a time; the others go on rendering
+				if (!rl.owns_lock()) continue;
+				const auto now = std::chrono::steady_clock::now();
+				const bool last = done >= total_tiles;
+				if (last || std::chrono::duration<float>(now - last_report).count() >= report_interval) {
+					std::unique_lock<std::shared_mutex> lock(films);
+					if (!read_back()) {
+						note_error();
+						abort_all = true;
+						break;
+					}
+					lock.unlock();
+					report_fn(Render_Report{float(traced_tiles.load()) / float(total_tiles), accumulator_to_image()});
+					last_report = now;
+				}
+			}
+		};
+		if (ok) {
+			std::vector<std::thread> th;
+			for (size_t k = 1; k < n_dev; k++) th.emplace_back(device_loop, k);
+			device_loop(0);
+			for (auto& t : th) t.join();
+			if (!abort_all) {
+				std::unique_lock<std::shared_mutex> lock(films);
+				if (!read_back()) note_error();
+			}
+		}
+		failed = first_error;
+		for (ptx_frame_t p : parts) ptx_frame_destroy(p);
+		ptx_frame_destroy(total), ptx_frame_destroy(shown);
+		render_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - render_start).count();
+		running = false;
+	}
+
 	bool scene_use_bvh = true;
-	int device = 0;
-	uint32_t seed = 1, tiles_per_batch = 128;   // 128 tiles of 100x100x50 = 64 M paths, one pass of the library
-	ptx_scene_t scene = nullptr;
+	std::vector<int> devices{0};
+	uint32_t seed = 1, render_seed = 1, tiles_per_batch = 128;   // 128 tiles of 100x100x50 = 64 M paths, one pass of the library
+	std::vector<ptx_scene_t> scenes;   // one per entry of `devices`
 	PtxCamera camera{};
 	std::vector<PtxTile> tiles;
 	std::vector<int64_t> accumulator;          // 40.24 fixed point, 3 per pixel (pathtracer.h:80-83)
 	std::vector<uint32_t> accumulator_samples;
+	uint32_t accumulator_w = 0;
 	uint32_t total_tiles = 0;
 	std::atomic<uint32_t> traced_tiles{0};
 	std::atomic<bool> running{false}, stop{false};

@@ -90,6 +90,11 @@ class Oracle:
         L.orc_philox_units.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, abi.f32p]
         L.orc_env_evaluate.argtypes = [vp, C.c_uint32, abi.f32p, abi.f32p]
         L.orc_camera_ray.argtypes = [C.POINTER(abi.PtxCamera), C.c_uint32, C.c_uint32, C.c_float, C.c_float, rayp]
+        L.orc_delta_incoming.argtypes = [C.c_uint32, abi.f32p, C.c_float, C.c_float, C.c_float, abi.f32p, abi.f32p, C.c_uint32, abi.f32p]
+        L.orc_sampler_rect.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_uint32, abi.f32p]
+        L.orc_sampler_cosine.argtypes = [C.c_uint32, C.c_uint32, abi.f32p]
+        L.orc_camera_sample_rays.argtypes = [C.POINTER(abi.PtxCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, rayp]
+        L.orc_philox_block.argtypes = [abi.u32p, abi.u32p, abi.u32p]
 
     # ---- scenes
     def scene(self, desc):
@@ -168,10 +173,43 @@ class Oracle:
         self.L.orc_philox_units(seed, pixel, sample, n, abi.fptr(out))
         return out
 
+    def delta_incoming(self, ltype, color, intensity, inner, outer, T, pts):
+        return _delta_incoming(self.L.orc_delta_incoming, ltype, color, intensity, inner, outer, T, pts)
+
+    def sampler_rect(self, seed, sx, sy, n):
+        out = np.zeros((n, 3), dtype=np.float32)
+        self.L.orc_sampler_rect(seed, sx, sy, n, abi.fptr(out))
+        return out
+
+    def sampler_cosine(self, seed, n):
+        out = np.zeros((n, 4), dtype=np.float32)
+        self.L.orc_sampler_cosine(seed, n, abi.fptr(out))
+        return out
+
+    def camera_sample_rays(self, cam, seed, px, py, n):
+        r = np.zeros(n, dtype=abi.RAY_DTYPE)
+        self.L.orc_camera_sample_rays(C.byref(cam), seed, px, py, n, _ptr(r, rayp))
+        return r
+
+    def philox_block(self, counter4, key2):
+        c, k = np.array(counter4, dtype=np.uint32), np.array(key2, dtype=np.uint32)
+        out = np.zeros(4, dtype=np.uint32)
+        self.L.orc_philox_block(abi.uptr(c), abi.uptr(k), abi.uptr(out))
+        return out
+
     def camera_ray(self, cam, px, py, a, b):
         r = np.zeros(1, dtype=abi.RAY_DTYPE)
         self.L.orc_camera_ray(C.byref(cam), px, py, a, b, _ptr(r, rayp))
         return r
+
+
+def _delta_incoming(fn, ltype, color, intensity, inner, outer, T, pts):
+    color = np.array(color, dtype=np.float32)
+    T = None if T is None else np.ascontiguousarray(T, dtype=np.float32).reshape(16)
+    pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((len(pts), 7), dtype=np.float32)
+    fn(ltype, abi.fptr(color), intensity, inner, outer, _ptr(T, abi.f32p), abi.fptr(pts), len(pts), abi.fptr(out))
+    return out
 
 
 class OracleScene:
@@ -292,6 +330,10 @@ class Ref:
         L.ref_fuzz_mesh.restype = C.c_uint32
         L.ref_fuzz_mesh.argtypes = [C.c_uint32, abi.f32p, C.c_uint32, rayp, C.c_uint32]
         L.ref_ray_make.argtypes = [abi.f32p, abi.f32p, abi.f32p, rayp]
+        L.ref_tonemap.argtypes = [C.c_uint32, C.c_uint32, abi.f32p, C.c_float, u8p]
+        L.ref_delta_incoming.argtypes = [C.c_uint32, abi.f32p, C.c_float, C.c_float, C.c_float, abi.f32p, abi.f32p, C.c_uint32, abi.f32p]
+        L.ref_sampler_rect.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_uint32, abi.f32p]
+        L.ref_sampler_cosine.argtypes = [C.c_uint32, C.c_uint32, abi.f32p]
 
     def mesh(self, verts, indices, use_bvh=True, max_leaf=4, id_coded=True, nodes=None):
         verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 8)
@@ -329,6 +371,26 @@ class Ref:
         r = np.zeros(1, dtype=abi.RAY_DTYPE)
         self.L.ref_ray_make(abi.fptr(o), abi.fptr(d), _ptr(T, abi.f32p), _ptr(r, rayp))
         return r
+
+    def tonemap(self, rgb, w, h, exposure):
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32).reshape(-1, 3)
+        assert len(rgb) == w * h
+        out = np.zeros((w * h, 4), dtype=np.uint8)
+        self.L.ref_tonemap(w, h, abi.fptr(rgb), exposure, _ptr(out, u8p))
+        return out
+
+    def delta_incoming(self, ltype, color, intensity, inner, outer, T, pts):
+        return _delta_incoming(self.L.ref_delta_incoming, ltype, color, intensity, inner, outer, T, pts)
+
+    def sampler_rect(self, seed, sx, sy, n):
+        out = np.zeros((n, 3), dtype=np.float32)
+        self.L.ref_sampler_rect(seed, sx, sy, n, abi.fptr(out))
+        return out
+
+    def sampler_cosine(self, seed, n):
+        out = np.zeros((n, 4), dtype=np.float32)
+        self.L.ref_sampler_cosine(seed, n, abi.fptr(out))
+        return out
 
     def triangle_hit(self, verts24, ray):
         verts24 = np.ascontiguousarray(verts24, dtype=np.float32).reshape(24)

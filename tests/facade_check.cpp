@@ -97,7 +97,31 @@ int main(int argc, char** argv) {
 		PT::HDR_Image img = pt.accumulator_to_image();
 		EXPECT(img.w == 250 && img.h == 250 && img.rgb.size() == 250u * 250u * 3u);
 
-		// add_samples: the same film gets 60 more samples per pixel; the estimate stays where it was
+		const std::vector<int64_t> first_acc = pt.accumulator_rgb();
+
+		// the same render with its tiles dealt to two workers (two scene copies and two films on this GPU, added at the
+		// end -- the path several GPUs take): the accumulator is the single-worker one bit for bit
+		{
+			PT::Pathtracer two;
+			two.set_devices({0, 0});
+			two.set_tiles_per_batch(4);
+			two.render(desc, cam, nullptr, &quit);
+			two.wait();
+			EXPECT(two.error().empty());
+			EXPECT(two.samples_per_pixel_min() == 60u && two.samples_per_pixel_max() == 60u);
+			EXPECT(two.accumulator_rgb() == first_acc);
+			PT::Pathtracer three;
+			three.set_devices({0, 0, 0});
+			three.set_report_interval(0.0f);
+			int reports = 0;
+			three.render(desc, cam, [&](PT::Pathtracer::Render_Report&&) { reports++; }, &quit);
+			three.wait();
+			EXPECT(three.error().empty() && reports >= 1);
+			EXPECT(three.accumulator_rgb() == first_acc);
+		}
+
+		// add_samples: the same film gets 60 more samples per pixel -- NEW samples (the sample index continues), so the
+		// accumulator is not twice the first pass, and the estimate stays where it was
 		progress.clear();
 		pt.render(desc, cam, [&](PT::Pathtracer::Render_Report&& r) {
 			progress.push_back(r.first);
@@ -109,6 +133,25 @@ int main(int argc, char** argv) {
 		EXPECT(pt.error().empty() && progress.back() == 1.0f);
 		EXPECT(pt.samples_per_pixel_min() == 120u && pt.samples_per_pixel_max() == 120u);
 		EXPECT(std::fabs(last_mean - first_mean) < 0.05 * first_mean);
+		{
+			const std::vector<int64_t>& acc2 = pt.accumulator_rgb();
+			size_t doubled = 0, lit = 0;
+			for (size_t i = 0; i < acc2.size(); i++)
+				if (first_acc[i] != 0) lit++, doubled += acc2[i] == 2 * first_acc[i];
+			// a replay of the same samples would double every entry; fresh samples double one only by chance (a floor pixel's
+			// sum is 4 x the number of its samples that reached the lamp, so equal counts in both passes are not rare)
+			EXPECT(lit > 1000 && doubled < lit / 2);
+			// ... and it equals one 120-sample render of a fresh film with the same seed: same streams, same sums per tile
+			PT::Pathtracer whole;
+			PtxCamera cam120 = cam;
+			cam120.film_samples = 120;
+			whole.render(desc, cam120, nullptr, &quit);
+			whole.wait();
+			EXPECT(whole.error().empty() && whole.samples_per_pixel_min() == 120u);
+			double m = 0.0;
+			for (float v : whole.accumulator_to_image().rgb) m += v;
+			EXPECT(std::fabs(m / double(acc2.size()) - last_mean) < 1e-4 * last_mean);
+		}
 
 		// quit set before the first batch: nothing is traced, the film is cleared (no add_samples) and stays empty
 		quit = true;

@@ -20,6 +20,13 @@ Fixtures (all little-endian numpy .npz):
                        reference's Indexed_Mesh::from_halfedge_mesh(SplitEdges) produces them, instance
                        transforms, materials, cameras) -- checked here against the reference's own
                        loader byte for byte before it is written
+  hits_cow.npz         the cow mesh of media/js3d/cow.js3d (a shared-vertex mesh with thin triangles; its arrays are in
+                       scene_refract_cow_cbox.npz): 4096 rays aimed into its box plus 4096 rays grazing its surface, results of
+                       the reference's Tri_Mesh::hit through the reference's own BVH builder
+  hits_sphere5.npz     Util::sphere_mesh(1, 5), 20,480 triangles: positions, indices, rays, results
+  builder2.npz         node arrays of the reference builder (digest + head) for those two meshes
+  probes2.npz          HDR_Image::tonemap_to, Delta_Lights::{Point,Directional,Spot}::incoming through Light_Instance,
+                       Samplers::Rect and Samplers::Hemisphere::Cosine on seeded inputs
   image_<name>_<mode>.npz   64x64 renders of those scenes by the CPU checker with the reference's
                        mt19937-per-tile stream (the reference's Pathtracer itself cannot be built in this
                        image: pathtracer.cpp needs SDL.h): 4096 spp image, and the RMSE of an independent
@@ -40,6 +47,8 @@ import scenes  # noqa: E402
 from _oracle import Oracle, Ref  # noqa: E402
 import ctypes as C  # noqa: E402
 import struct  # noqa: E402
+sys.path.insert(0, HERE)
+from make_golden_rays import grazing_rays, mesh_rays  # noqa: E402
 
 MEDIA = "/root/reference/media/js3d"
 
@@ -157,32 +166,72 @@ def digest(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
 
 
-def mesh_rays(verts, n, seed):
-    """Rays aimed into the mesh's bounding box from around it (about half of them hit something)."""
-    g = np.random.Generator(np.random.Philox(key=seed))
-    lo, hi = verts[:, :3].min(axis=0), verts[:, :3].max(axis=0)
-    c, e = (lo + hi) / 2, (hi - lo)
-    o = c + (g.random((n, 3)) * 2 - 1) * e * 1.2
-    t = lo + g.random((n, 3)) * e
-    d = t - o
-    d /= np.linalg.norm(d, axis=1, keepdims=True)
-    r = np.zeros(n, dtype=abi.RAY_DTYPE)
-    r["o"] = o.astype(np.float32)
-    r["d"] = synth._unit_f32(d)
-    r["tmin"], r["tmax"] = 0.0, np.inf
-    # a quarter of the rays get finite bounds, as shadow rays have
-    r["tmin"][::4] = 1e-5
-    r["tmax"][::4] = (g.random(len(r["tmax"][::4])) * np.linalg.norm(e)).astype(np.float32)
-    return r
-
-
 def hit_fields(res):
     h = res["hits"]
     return dict(distance_bits=h["distance"].view(np.uint32), prim=h["prim"], pos=res["pos"], normal=res["normal"], uv=res["uv"])
 
 
+def more_fixtures(ref):
+    out = {}
+    # ---- cow mesh (arrays from the committed descriptor of refract_cow_cbox.js3d, itself checked against the reference loader)
+    verts, idx = scenes.cow_mesh()
+    rays = np.concatenate([mesh_rays(verts, N_RAYS, 1003), grazing_rays(verts, idx, N_RAYS, 1004)])
+    m = ref.mesh(verts, idx, use_bvh=True, id_coded=False)
+    full = m.hit(rays, full=True)
+    m.close()
+    m = ref.mesh(verts, idx, use_bvh=True, id_coded=True)
+    ids = m.hit(rays, full=True)
+    nodes = m.nodes()
+    m.close()
+    f = hit_fields(ids)
+    f["normal"], f["uv"] = full["normal"], full["uv"]
+    np.savez_compressed(os.path.join(HERE, "hits_cow.npz"), rays=rays.view(np.float32).reshape(-1, 8), **f)
+    out["cow_nodes_sha256"], out["cow_nodes_head"], out["cow_n_nodes"] = digest(nodes), nodes[:64], len(nodes)
+    print("cow: hit fraction", (f["prim"] != abi.PTX_NO_HIT).mean(), "nodes", len(nodes))
+
+    # ---- Util::sphere_mesh(1, 5)
+    verts, idx = ref.sphere_mesh(1.0, 5)
+    rays = np.concatenate([mesh_rays(verts, N_RAYS, 1005), grazing_rays(verts, idx, N_RAYS // 2, 1006)])
+    m = ref.mesh(verts, idx, use_bvh=True, id_coded=True)
+    ids = m.hit(rays, full=True)
+    nodes = m.nodes()
+    m.close()
+    f = hit_fields(ids)
+    del f["normal"], f["uv"]       # id-coded normals; the level-3 sphere fixture covers attribute interpolation
+    assert idx.max() < 65536
+    np.savez_compressed(os.path.join(HERE, "hits_sphere5.npz"), positions=verts[:, :3].copy(), indices=idx.astype(np.uint16),
+                        rays=rays.view(np.float32).reshape(-1, 8), **f)
+    out["sphere5_nodes_sha256"], out["sphere5_nodes_head"], out["sphere5_n_nodes"] = digest(nodes), nodes[:64], len(nodes)
+    print("sphere5: tris", len(idx), "hit fraction", (f["prim"] != abi.PTX_NO_HIT).mean(), "nodes", len(nodes))
+    np.savez_compressed(os.path.join(HERE, "builder2.npz"), **out)
+
+    # ---- probes
+    g = np.random.Generator(np.random.Philox(key=2025))
+    p = {}
+    w, h = 64, 48
+    rgb = (g.random((w * h, 3), dtype=np.float32) * 4).astype(np.float32)
+    rgb[:64] *= 1e-3          # the linear segment of the sRGB curve
+    rgb[64:128] *= 30.0       # saturated
+    p.update(tonemap_rgb=rgb, tonemap_size=np.array([w, h], dtype=np.uint32), tonemap_exposure=np.array([1.0, 0.5, 2.5], dtype=np.float32),
+             tonemap_rgba=np.stack([ref.tonemap(rgb, w, h, float(e)) for e in (1.0, 0.5, 2.5)]))
+    pts = (g.random((512, 3), dtype=np.float32) * 6 - 3).astype(np.float32)
+    T = scenes.trs((0.5, 1.0, -2.0), axis=(1, 2, 3), deg=40.0, scale=(1.5, 0.7, 2.0))
+    p.update(light_points=pts, light_T=T, light_params=np.array([1.0, 0.9, 0.8, 2.0, 40.0, 70.0], dtype=np.float32))
+    for t, name in ((abi.PTX_LIGHT_POINT, "point"), (abi.PTX_LIGHT_DIRECTIONAL, "directional"), (abi.PTX_LIGHT_SPOT, "spot")):
+        p[f"light_{name}_identity_bits"] = ref.delta_incoming(t, (1.0, 0.9, 0.8), 2.0, 40.0, 70.0, None, pts).view(np.uint32)
+        p[f"light_{name}_transformed_bits"] = ref.delta_incoming(t, (1.0, 0.9, 0.8), 2.0, 40.0, 70.0, T, pts).view(np.uint32)
+    p.update(rect_unit_bits=ref.sampler_rect(4660, 1.0, 1.0, 256).view(np.uint32), rect_3x05_bits=ref.sampler_rect(7, 3.0, 0.5, 256).view(np.uint32),
+             cosine_bits=ref.sampler_cosine(462, 1024).view(np.uint32))
+    np.savez_compressed(os.path.join(HERE, "probes2.npz"), **p)
+
+
 def main():
     ref = Ref()
+    if len(sys.argv) > 1 and sys.argv[1] == "more":     # only the fixtures of more_fixtures()
+        more_fixtures(ref)
+        for f in sorted(os.listdir(HERE)):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+        return
     out = {}
 
     # ---- fuzz mesh
@@ -312,6 +361,7 @@ def main():
     p.update(env_image=img, env_dirs=edirs.astype(np.float32), env_bilinear=ref.env_sphere_evaluate(img, abi.PTX_SAMPLER_BILINEAR, edirs),
              env_nearest=ref.env_sphere_evaluate(img, abi.PTX_SAMPLER_NEAREST, edirs))
     np.savez_compressed(os.path.join(HERE, "probes.npz"), **p)
+    more_fixtures(ref)
     scene_and_image_fixtures(ref)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

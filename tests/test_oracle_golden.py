@@ -183,3 +183,96 @@ def test_probes(oracle):
         got = np.stack([sc.env_evaluate(0, d) for d in p["env_dirs"]])
         sc.close()
         np.testing.assert_allclose(got, p[key], rtol=0, atol=2e-6)
+
+
+def sphere5_mesh():
+    g = load("hits_sphere5.npz")
+    return positions_to_verts(g["positions"]), g["indices"].astype(np.uint32), g
+
+
+def test_cow_and_sphere5_hits(oracle):
+    """The cow of media/js3d/cow.js3d (shared vertices, thin triangles; half of the rays graze its surface) and
+    Util::sphere_mesh(1, 5), 20,480 triangles: Tri_Mesh::hit of the reference through its own builder."""
+    g = load("hits_cow.npz")
+    verts, idx = scenes.cow_mesh()
+    check_mesh_hits(oracle, verts, idx, rays_of(g["rays"]), g)
+    verts, idx, g = sphere5_mesh()
+    check_mesh_hits(oracle, verts, idx, rays_of(g["rays"]), g, check_attrs=False)
+
+
+def test_builder_matches_reference_builder_cow_sphere5(oracle):
+    import hashlib
+    g = load("builder2.npz")
+    cases = {"cow": scenes.cow_mesh(), "sphere5": sphere5_mesh()[:2]}
+    for name, (verts, idx) in cases.items():
+        sb = abi.SceneBuilder()
+        sc = oracle.mesh_scene(sb.mesh_desc(verts, idx, use_bvh=True, max_leaf_size=4))
+        nodes = sc.mesh_nodes()
+        sc.close()
+        assert len(nodes) == int(g[f"{name}_n_nodes"])
+        assert nodes[:64].tobytes() == g[f"{name}_nodes_head"].tobytes()
+        assert hashlib.sha256(nodes.tobytes()).digest() == g[f"{name}_nodes_sha256"].tobytes()
+        b = capi.Bvh(verts=verts, indices=idx, max_leaf_size=4)
+        assert b.nodes().tobytes() == nodes.tobytes()
+        b.close()
+
+
+def test_probes2_tonemap(oracle):
+    """HDR_Image::tonemap_to (util/hdr_image.cpp:201-225): the checker and the product's ptx_tonemap give the reference's bytes."""
+    p = load("probes2.npz")
+    for e, want in zip(p["tonemap_exposure"], p["tonemap_rgba"]):
+        assert (oracle.tonemap(p["tonemap_rgb"], float(e)) == want).all()
+        assert (capi.tonemap(p["tonemap_rgb"], float(e)) == want).all()
+
+
+def test_probes2_delta_lights(oracle):
+    """Delta_Lights::{Point,Directional,Spot}::incoming through PT::Light_Instance (delta_light.cpp:7-40, instance.h:74-91)."""
+    p = load("probes2.npz")
+    c = p["light_params"]
+    for t, name in ((abi.PTX_LIGHT_POINT, "point"), (abi.PTX_LIGHT_DIRECTIONAL, "directional"), (abi.PTX_LIGHT_SPOT, "spot")):
+        for T, key in ((None, "identity"), (p["light_T"], "transformed")):
+            got = oracle.delta_incoming(t, c[:3], float(c[3]), float(c[4]), float(c[5]), T, p["light_points"])
+            want = p[f"light_{name}_{key}_bits"]
+            if t == abi.PTX_LIGHT_SPOT:   # atan2 in the falloff: value comparison for the radiance, bits for the geometry
+                np.testing.assert_allclose(got[:, :3], want.view(np.float32)[:, :3], rtol=0, atol=2e-6)
+                assert (bits(got[:, 3:]) == want[:, 3:]).all()
+            else:
+                assert (bits(got) == want).all(), (name, key)
+
+
+def test_probes2_samplers(oracle):
+    """Samplers::Rect (samplers.cpp:7-19, including which of its two draws scales x under g++) and
+    Hemisphere::Cosine (samplers.cpp:67-83); Camera::sample_ray's pixel offset is that Rect sample."""
+    p = load("probes2.npz")
+    assert (bits(oracle.sampler_rect(4660, 1.0, 1.0, 256)) == p["rect_unit_bits"]).all()
+    assert (bits(oracle.sampler_rect(7, 3.0, 0.5, 256)) == p["rect_3x05_bits"]).all()
+    np.testing.assert_allclose(oracle.sampler_cosine(462, 1024), p["cosine_bits"].view(np.float32), rtol=0, atol=2e-6)
+    # the checker's Camera::sample_ray in the reference's draw order == the ray through the reference's Rect sample
+    cam = abi.PtxCamera()
+    cam.vertical_fov, cam.aspect_ratio, cam.film_width, cam.film_height, cam.film_samples, cam.film_max_ray_depth = 50.0, 1.5, 30, 20, 1, 4
+    T = scenes.trs((1, 2, 3), axis=(0, 1, 0), deg=25)
+    for i in range(16):
+        cam.camera_to_world[i] = float(T[i])
+    offs = p["rect_unit_bits"].view(np.float32)
+    rays = oracle.camera_sample_rays(cam, 4660, 7, 11, 64)
+    for k in range(64):
+        want = oracle.camera_ray(cam, 7, 11, float(offs[k, 0]), float(offs[k, 1]))
+        assert rays[k:k + 1].tobytes() == want.tobytes()
+
+
+PHILOX_KAT = [   # Random123's published known-answer vectors for philox4x32, 10 rounds: counter, key, expected
+    ([0x00000000] * 4, [0x00000000] * 2, [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+def test_philox_known_answers(oracle):
+    for c, k, want in PHILOX_KAT:
+        assert oracle.philox_block(c, k).tolist() == want
+    # the path stream: draw i of (seed, pixel, sample) is word i % 4 of the block with counter (i / 4, pixel, sample, 0)
+    seed, pixel, sample = 0x0123456789ABCDEF, 4242, 17
+    units = oracle.philox_units(seed, pixel, sample, 12)
+    for blk in range(3):
+        words = oracle.philox_block([blk, pixel, sample, 0], [seed & 0xFFFFFFFF, seed >> 32])
+        assert (units[4 * blk:4 * blk + 4] == np.ldexp(words.astype(np.float32), -32)).all()

@@ -203,6 +203,8 @@ def roofline_block(kernel_ms, n, work, ref_nodes_per_ray, ref_tris_per_ray):
       valu_lanes   lane-operations executed / (CUs x 64 lanes x cycles): issue rate x lanes active per instruction
       l2_requests  bytes the traversal requests (64 B per two-child node, 48 B per triangle, ray, hit, order index;
                    device-side visit counts of this run) / L2 aggregate peak
+      l1_accesses  vector-L1 accesses (one per lane per 16-byte load of its own record) / (CUs x cycles): the L1
+                   looks up about one line per clock
       hbm_fabric   L2<->fabric bytes (FETCH_SIZE + WRITE_SIZE) / HBM peak: an upper bound on DRAM traffic, since
                    Infinity Cache hits are counted
     `frac` of the block is hbm_fabric's (the memory roof the contract names); `nearest_roof` says which one binds."""
@@ -227,9 +229,15 @@ def roofline_block(kernel_ms, n, work, ref_nodes_per_ray, ref_tris_per_ray):
         roofs["valu_lanes"] = {"frac": round(lanes, 4), "SQ_THREAD_CYCLES_VALU": c["SQ_THREAD_CYCLES_VALU"],
                                "lanes_active_per_instruction": round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"], 1),
                                "achieved": round(c["SQ_THREAD_CYCLES_VALU"] / sec / 1e12, 2), "peak": round(CUS * LANES_PER_CU_CYCLE * 2.4e9 / 1e12, 2), "unit": "T lane-ops/s at 2.4 GHz"}
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+            # every lane of a traversal step reads its own node or triangle record: four 16-byte accesses per node, three
+            # per triangle, each a line lookup of its own in the CU's vector L1, which serves about one per clock
+            acc = c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+            roofs["l1_accesses"] = {"frac": round(acc / (cycles * CUS), 4), "TCP_TOTAL_CACHE_ACCESSES_sum": acc, "accesses_per_ray": round(acc / n, 1),
+                                    "peak": "one vector-L1 access per clock per CU"}
         if "TD_TD_BUSY_sum" in c:
-            roofs["vector_memory_return"] = {"frac": round(c["TD_TD_BUSY_sum"] / (cycles * CUS), 4), "TD_TD_BUSY_sum": c["TD_TD_BUSY_sum"]}
-    nearest = max(roofs, key=lambda k: roofs[k]["frac"])
+            roofs["vector_memory_return_busy"] = {"busy_frac": round(c["TD_TD_BUSY_sum"] / (cycles * CUS), 4), "TD_TD_BUSY_sum": c["TD_TD_BUSY_sum"]}
+    nearest = max((k for k in roofs if "frac" in roofs[k]), key=lambda k: roofs[k]["frac"])
     ref_bytes = 32 + 8 + 32 * ref_nodes_per_ray + 36 * ref_tris_per_ray
     ref_gbs = ref_bytes * n / sec / 1e9
     primary = roofs.get("hbm_fabric") or roofs["l2_requests"]
@@ -245,7 +253,7 @@ def roofline_block(kernel_ms, n, work, ref_nodes_per_ray, ref_tris_per_ray):
                                                   "32 B per box + 36 B per triangle, counts from the CPU checker) would move for the same batch, over this kernel's time: "
                                                   "an equivalent-work figure, not bytes this kernel moves -- the culled order skips about 3/4 of those visits"},
             "note": "achieved/peak/frac = L2<->fabric bytes per launch over live kernel time against HBM peak (Infinity Cache hits included, so an upper bound on DRAM "
-                    "traffic); nearest_roof names the roof that binds: vector-ALU issue and the vector-memory return path are both near saturation with under half the lanes active per instruction; DRAM is not"}
+                    "traffic); nearest_roof names the roof that binds: the vector L1's access rate (one record piece per lane per clock) and vector-ALU issue are both near saturation, with under half the lanes active per instruction; DRAM is not"}
 
 
 def free_port():

@@ -32,6 +32,17 @@ struct alignas(64) Node2 {
 };
 static_assert(sizeof(Node2) == 64, "one cache line");
 
+// Interior node of the four-wide form of the same tree: a binary node with its interior children replaced by
+// their children (where the grandchild's box lies inside the child's, so that passing the grandchild's slab test
+// implies passing the child's -- the chain of tests PT::BVH::hitRecursive makes on the way down, bvh.cpp:278-286).
+// Unused children carry REF_NONE4 and a zero box.
+constexpr uint32_t REF_NONE4 = 0xFFFFFFFEu;
+struct alignas(128) Node4 {
+	Node2 half[2];   // children 0,1 and children 2,3, each pair laid out as a binary node's pair (one cache line)
+};
+static_assert(sizeof(Node4) == 128, "two cache lines");
+
+
 // One triangle as the intersector wants it: v0 and the two edges e1 = v1 - v0, e2 = v2 - v0
 // (the subtractions Triangle::hit performs per call, tri_mesh.cpp:57-59, done once in fp32
 // on the host: same operands, same rounding, same bits).
@@ -58,6 +69,8 @@ struct MeshRec {
 	uint32_t n_tris;
 	uint32_t is_list;       // List<Triangle>: no box test, fold over all n_tris (list.h:25-32)
 	uint32_t tame;          // every box coordinate is 0 or in [2^-70, 2^39): the short division form is exact
+	uint32_t root4_ref;     // root of the four-wide form (leaf ref or index relative to node4_base); valid when SceneRec::nodes4 is set
+	uint32_t node4_base;
 };
 
 // One PT::Instance (instance.h:15-40).  Matrices column-major, element [col*4+row].
@@ -72,6 +85,7 @@ struct InstRec {
 
 struct SceneRec {
 	const Node2* nodes;       // all trees' interior nodes
+	const Node4* nodes4;      // four-wide form of the mesh trees (single-mesh scenes only, else null)
 	const TriGeom* tris;
 	const TriAttr* attrs;
 	const MeshRec* meshes;

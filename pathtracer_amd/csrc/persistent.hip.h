@@ -20,6 +20,12 @@ constexpr int REFILL_MIN_IDLE = 20;   // refill when at least this many of the 6
 constexpr int TRI_MIN_LANES = 1;      // reference order: run the triangle step when at least this many lanes stand in a leaf
 constexpr int PARK_MIN_LANES = 32;    // culled order: run the triangle phase when this many lanes have a leaf parked ...
 constexpr int STUCK_MAX_LANES = 16;   // ... or this many lanes cannot go on walking until their parked leaf is tested
+#ifndef PTX_WALK_STEPS
+#define PTX_WALK_STEPS 1   // box steps per loop iteration of the culled order, before the triangle phase is considered
+#endif
+#ifndef PTX_WIDE_WAVES
+#define PTX_WIDE_WAVES 5   // waves per SIMD the four-wide instance is compiled for (96 VGPRs)
+#endif
 #ifndef PTX_LDS_SLOTS
 #define PTX_LDS_SLOTS 12
 #endif
@@ -31,8 +37,9 @@ constexpr unsigned long long WAVE_CHUNK = 64;     // consecutive ray slots a wav
 
 // The culled-order instance needs 82 VGPRs left alone, two above the 80 that let six waves share a
 // SIMD; held to 80 it runs 2 % faster on grouped rays (measured), the few spilled values being cold.
-template<int MODE, bool ANY>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_mesh_persistent(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, PtxHit* __restrict__ hits,
+// WIDE: walk the four-wide form of the tree (SceneRec::nodes4; culled order only).
+template<int MODE, bool ANY, bool WIDE = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? PTX_WIDE_WAVES : 6, WIDE ? PTX_WIDE_WAVES : 6))) k_mesh_persistent(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, PtxHit* __restrict__ hits,
                                                          float* __restrict__ bary, uint32_t* __restrict__ inst, uint8_t* __restrict__ occluded,
                                                          unsigned long long* __restrict__ next_ray, const int refill_min_idle,
                                                          const uint32_t* __restrict__ order, uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count,
@@ -40,6 +47,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
 	const MeshRec mesh = sc.meshes[0];
 	const TriGeom* __restrict__ tris = sc.tris + mesh.tri_base;
 	const Node2* __restrict__ nodes = sc.nodes + mesh.node_base;
+	const Node4* __restrict__ nodes4 = WIDE ? sc.nodes4 + mesh.node4_base : nullptr;
+	static_assert(!WIDE || MODE == MODE_CULLED, "the four-wide tree serves the culled order only");
 	const unsigned lane = threadIdx.x & 63u;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
@@ -131,7 +140,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
 						sp = 0;
 						tri_k = 0;
 						if (slab_test<true>(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], r, inv, tn))
-							ref = mesh.root_ref;
+							ref = WIDE ? mesh.root4_ref : mesh.root_ref;
 						else
 							ref = REF_DONE;
 					} else {
@@ -152,22 +161,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
 			// iteration with a few.  A parked leaf is tested later than it would have been, so the
 			// cull limit the lane uses meanwhile is looser (never tighter) than it could be: the
 			// outcome is unchanged because the culled mode's result does not depend on test order.
-			const unsigned long long on_node = __ballot(!(ref & REF_LEAF));
+#pragma unroll
+			for (int step = 0; step < PTX_WALK_STEPS; step++) {
+				const unsigned long long on_node = __ballot(!(ref & REF_LEAF));
 #ifdef PTX_PROFILE_LANES
-			prof_iters++, prof_node_lanes += __popcll(on_node), prof_node_iters += on_node != 0ull, prof_busy += __popcll(__ballot(have_ray));
+				prof_iters++, prof_node_lanes += __popcll(on_node), prof_node_iters += on_node != 0ull, prof_busy += __popcll(__ballot(have_ray));
 #endif
-			if (on_node != 0ull) {
-				if (!(ref & REF_LEAF)) {
-					const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
-					const float4 n0 = p[0], n1 = p[1], n2 = p[2];
-					const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
-					node_decide<MODE, ANY, true, true>(n0, n1, n2, kids, r, inv, st, 0, sp, ref, cur.hit, cur.distance);
+				if (on_node != 0ull) {
+					if (!(ref & REF_LEAF)) {
+						if (WIDE) {
+							node4_decide<ANY>(nodes4 + (ref & REF_INDEX_MASK), r, inv, st, sp, ref, cur.hit, cur.distance);
+						} else {
+							const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
+							const float4 n0 = p[0], n1 = p[1], n2 = p[2];
+							const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
+							node_decide<MODE, ANY, true, true>(n0, n1, n2, kids, r, inv, st, 0, sp, ref, cur.hit, cur.distance);
+						}
+					}
 				}
-			}
-			// one pop loop for both reasons to pop: no child taken, or a leaf reached and parked
-			if ((ref & REF_LEAF) && ref != REF_DONE && (ref == REF_NONE || pend == 0u)) {
-				if (ref != REF_NONE && (ref & 15u)) pend = ref;   // an empty leaf has nothing to test
-				pop_ref<MODE, ANY>(r, st, 0, sp, ref, cur.hit, cur.distance);
+				// one pop loop for both reasons to pop: no child taken, or a leaf reached and parked
+				if ((ref & REF_LEAF) && ref != REF_DONE && (ref == REF_NONE || pend == 0u)) {
+					if (ref != REF_NONE && (ref & 15u)) pend = ref;   // an empty leaf has nothing to test
+					pop_ref<MODE, ANY>(r, st, 0, sp, ref, cur.hit, cur.distance);
+				}
 			}
 			// ---- triangle phase: when enough leaves are parked, or too many lanes cannot go on
 			// (a second leaf reached, or the walk finished, while one is still parked)

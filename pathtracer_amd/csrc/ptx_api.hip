@@ -227,6 +227,81 @@ static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_pr
 	return PTX_OK;
 }
 
+// Four-wide form of a flattened binary tree: every interior child of a binary node is replaced by its own two
+// children when both of their boxes lie inside the child's box (coordinate by coordinate, exactly).  The slab
+// test is monotone under box inclusion -- subtraction, division and the min/max merges are -- so a ray that passes
+// a grandchild's test passes the skipped child's too, and the set of leaves reached is that of the binary tree.
+// (The reference builder can produce a child box that pokes out of its parent's, bvh.cpp:191-221: such a child
+// stays a child of the wide node, with its own box test.)
+static void widen_tree(const FlatTree& in, std::vector<Node4>& out, uint32_t& root_ref, uint32_t& skipped_levels) {
+	out.clear();
+	skipped_levels = 0;
+	root_ref = in.root_ref;
+	if (in.nodes.empty() || (in.root_ref & REF_LEAF)) return;
+	struct Kid {
+		float lo[3], hi[3];
+		uint32_t ref;   // binary-tree reference (leaf ref, or interior index | flags)
+	};
+	auto kids_of = [&](uint32_t idx, Kid k[2]) {
+		const Node2& n = in.nodes[idx];
+		for (int a = 0; a < 3; a++) k[0].lo[a] = n.lmin[a], k[0].hi[a] = n.lmax[a], k[1].lo[a] = n.rmin[a], k[1].hi[a] = n.rmax[a];
+		k[0].ref = n.lref, k[1].ref = n.rref;
+	};
+	auto inside = [](const Kid& g, const Kid& c) {
+		for (int a = 0; a < 3; a++)
+			if (!(g.lo[a] >= c.lo[a] && g.hi[a] <= c.hi[a])) return false;
+		return true;
+	};
+	// breadth of work: wide nodes are created in the order their binary parents are reached, depth first
+	std::vector<uint32_t> wide_of(in.nodes.size(), 0xFFFFFFFFu);
+	std::vector<uint32_t> stack{0u};
+	wide_of[0] = 0;
+	out.emplace_back();
+	while (!stack.empty()) {
+		const uint32_t b = stack.back();
+		stack.pop_back();
+		Kid two[2], four[4];
+		int n4 = 0;
+		kids_of(b, two);
+		for (int c = 0; c < 2; c++) {
+			bool opened = false;
+			if (!(two[c].ref & REF_LEAF)) {
+				Kid g[2];
+				kids_of(two[c].ref & REF_INDEX_MASK, g);
+				if (inside(g[0], two[c]) && inside(g[1], two[c])) {
+					four[n4++] = g[0], four[n4++] = g[1];
+					opened = true;
+					skipped_levels++;
+				}
+			}
+			if (!opened) four[n4++] = two[c];
+		}
+		Node4 w{};
+		uint32_t wref[4] = {REF_NONE4, REF_NONE4, REF_NONE4, REF_NONE4};
+		for (int c = 0; c < n4; c++) {
+			Node2& hf = w.half[c >> 1];
+			for (int a = 0; a < 3; a++) {
+				if (c & 1) hf.rmin[a] = four[c].lo[a], hf.rmax[a] = four[c].hi[a];
+				else hf.lmin[a] = four[c].lo[a], hf.lmax[a] = four[c].hi[a];
+			}
+			if (four[c].ref & REF_LEAF) {
+				wref[c] = four[c].ref;
+			} else {
+				const uint32_t bi = four[c].ref & REF_INDEX_MASK;
+				if (wide_of[bi] == 0xFFFFFFFFu) {
+					wide_of[bi] = uint32_t(out.size());
+					out.emplace_back();
+					stack.push_back(bi);
+				}
+				wref[c] = wide_of[bi] | (four[c].ref & REF_NOCULL);
+			}
+		}
+		w.half[0].lref = wref[0], w.half[0].rref = wref[1], w.half[1].lref = wref[2], w.half[1].rref = wref[3];
+		out[wide_of[b]] = w;
+	}
+	root_ref = 0;
+}
+
 template<typename T> static int upload(PtxScene* s, const std::vector<T>& v, const T*& dev) {
 	dev = nullptr;
 	if (v.empty()) return PTX_OK;
@@ -254,6 +329,8 @@ static int check_mesh_desc(const PtxMeshDesc& m) {
 
 struct SceneBuild {
 	std::vector<Node2> nodes;
+	std::vector<Node4> nodes4;
+	bool want_wide = false;   // single-mesh scenes: also build the four-wide form of the tree
 	std::vector<TriGeom> tris;
 	std::vector<TriAttr> attrs;
 	std::vector<MeshRec> meshes;
@@ -299,6 +376,14 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 		rec.tame = ft.tame ? 1 : 0;
 		for (int k = 0; k < 3; k++) rec.root_min[k] = bvh.nodes[0].bmin[k], rec.root_max[k] = bvh.nodes[0].bmax[k];
 		sb.nodes.insert(sb.nodes.end(), ft.nodes.begin(), ft.nodes.end());
+		if (sb.want_wide) {
+			std::vector<Node4> wide;
+			uint32_t skipped = 0;
+			widen_tree(ft, wide, rec.root4_ref, skipped);
+			rec.node4_base = uint32_t(sb.nodes4.size());
+			sb.nodes4.insert(sb.nodes4.end(), wide.begin(), wide.end());
+			laps.lap("mesh: four-wide node layout");
+		}
 		// BVH::bbox (bvh.cpp:433-436)
 		for (int k = 0; k < 3; k++) mesh_box[k] = bvh.nodes[0].bmin[k], mesh_box[3 + k] = bvh.nodes[0].bmax[k];
 	} else {
@@ -342,6 +427,7 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 static int finish_geometry(PtxScene* s, SceneBuild& sb) {
 	BuildLaps laps;
 	if (int rc = upload(s, sb.nodes, s->rec.nodes)) return rc;
+	if (int rc = upload(s, sb.nodes4, s->rec.nodes4)) return rc;
 	if (int rc = upload(s, sb.tris, s->rec.tris)) return rc;
 	if (int rc = upload(s, sb.attrs, s->rec.attrs)) return rc;
 	if (int rc = upload(s, sb.meshes, s->rec.meshes)) return rc;
@@ -549,7 +635,12 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const Persiste
 		}
 		PTX_HIP(hipEventRecord(s->t_start[slot], s->stream));
 	}
-	if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
+	// Experiment switch: walk the four-wide form of the tree.  Measured 5 % slower than the binary walk on the 1M-triangle
+	// soup (half the loop iterations, but the same number of box tests and L1 accesses per ray, 8 more registers and
+	// therefore one wave per SIMD fewer), so it is off unless asked for.
+	static const bool wide = getenv("PTX_WIDE_TREE") && atoi(getenv("PTX_WIDE_TREE")) != 0;
+	if (culled && wide && s->rec.nodes4) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
+	else if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
 	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
 	if (pb.timed) {
 		PTX_HIP(hipEventRecord(s->t_stop[slot], s->stream));
@@ -630,6 +721,7 @@ int ptx_scene_create_mesh(int device, const PtxMeshDesc* mesh, ptx_scene_t* out)
 	PtxScene* s = nullptr;
 	if (int rc = open_device(device, &s)) return rc;
 	SceneBuild sb;
+	sb.want_wide = getenv("PTX_WIDE_TREE") && atoi(getenv("PTX_WIDE_TREE")) != 0;   // experiment switch, see launch_persistent
 	int rc = add_mesh(s, sb, *mesh);
 	if (!rc) rc = finish_geometry(s, sb);
 	if (!rc) {

@@ -312,6 +312,54 @@ __device__ __forceinline__ void node_decide(const float4 n0, const float4 n1, co
 	}
 }
 
+// The culled order's step on a four-wide node (device_types.h: Node4), for rays and trees in the exact-division
+// range.  Every child's accept/reject decision is the exact one (approximate test, exact test where the
+// approximation cannot tell: the node's half is then read again rather than kept in registers); the accepted
+// children are visited nearest first, the others pushed farthest first.  Leaves REF_NONE in `ref` when no child
+// is taken (the caller pops).
+template<bool ANY, typename StackType>
+__device__ __forceinline__ void node4_decide(const Node4* __restrict__ node, const Ray3& r, const RayInv& inv, StackType& st, int& sp, uint32_t& ref, bool run_hit,
+                                             float run_dist) {
+	const float limit = cull_limit<ANY>(r, run_hit, run_dist);
+	float key[4];
+	uint32_t val[4];
+	int n = 0;
+#pragma unroll
+	for (int half = 0; half < 2; half++) {
+		const float4* p = reinterpret_cast<const float4*>(node->half + half);
+		const float4 n0 = p[0], n1 = p[1], n2 = p[2];
+		const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
+		float tl, tr;
+		bool al, ar;
+		bool hl = slab_test_approx(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl, al);
+		bool hr = slab_test_approx(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr, ar);
+		if (__builtin_expect(__any(al || ar), 0)) {   // a ray grazing a box within rounding: decide it exactly
+			const volatile float4* q = reinterpret_cast<const volatile float4*>(node->half + half);
+			const float4 m0 = const_cast<const float4&>(q[0]), m1 = const_cast<const float4&>(q[1]), m2 = const_cast<const float4&>(q[2]);
+			if (al) hl = slab_test<true>(m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, r, inv, tl);
+			if (ar) hr = slab_test<true>(m1.z, m1.w, m2.x, m2.y, m2.z, m2.w, r, inv, tr);
+		}
+		const bool gl = hl && kids.x != REF_NONE4 && ((kids.x & REF_NOCULL) || !(tl > limit));
+		const bool gr = hr && kids.y != REF_NONE4 && ((kids.y & REF_NOCULL) || !(tr > limit));
+		key[2 * half] = gl ? tl : INFINITY, val[2 * half] = gl ? kids.x : REF_NONE4;
+		key[2 * half + 1] = gr ? tr : INFINITY, val[2 * half + 1] = gr ? kids.y : REF_NONE4;
+		n += (gl ? 1 : 0) + (gr ? 1 : 0);
+	}
+	// sorting network on four (key, value) pairs; rejected entries are told apart by their value, so an accepted
+	// child whose entry distance is +inf cannot be lost among them
+	auto cswap = [&](int a, int b) {
+		const bool sw = (val[a] == REF_NONE4 && val[b] != REF_NONE4) || (val[a] != REF_NONE4 && val[b] != REF_NONE4 && key[b] < key[a]);
+		const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];
+		const uint32_t va = sw ? val[b] : val[a], vb = sw ? val[a] : val[b];
+		key[a] = ka, key[b] = kb, val[a] = va, val[b] = vb;
+	};
+	cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
+	if (n > 3) st.push(sp++, val[3], key[3]);
+	if (n > 2) st.push(sp++, val[2], key[2]);
+	if (n > 1) st.push(sp++, val[1], key[1]);
+	ref = n > 0 ? val[0] : REF_NONE;
+}
+
 template<int MODE, bool ANY, bool FAST, bool STATS, typename StackType>
 __device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const Ray3& r, const RayInv& inv, StackType& st, const int base, int& sp,
                                           uint32_t& ref, bool run_hit, float run_dist, TraverseStats* stats) {

@@ -173,3 +173,15 @@ def test_many_instances_bit_exact(oracle):
         assert (got["inst"] == want["inst"]).all()
     sc.close()
     assert (want["hits"]["prim"] != abi.PTX_NO_HIT).mean() > 0.3
+
+
+def test_wide_tree_switch_is_bit_identical():
+    """PTX_WIDE_TREE=1 (an experiment switch: the four-wide form of the tree in the replenishing kernel) gives the
+    reference order's answers on every ray.  Read at library load, so it runs in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PTX_WIDE_TREE="1")
+    out = subprocess.check_output([sys.executable, os.path.join(root, "tools", "time_closest.py"), str(1 << 20), "2"], env=env, text=True, timeout=300)
+    assert "mismatches vs reference order 0" in out, out

@@ -64,7 +64,11 @@ enum {
 	PTX_NO_PERSISTENT = 1u << 8,
 	/* The batch is already ordered so that neighbouring rays travel together (camera rays in
 	 * pixel order, ...): skip the library's own grouping pass (results are identical). */
-	PTX_RAYS_COHERENT = 1u << 9
+	PTX_RAYS_COHERENT = 1u << 9,
+	/* ptx_render_tiles only: walk every ray of the render (extend and shadow rays) in the reference's visit order.
+	 * The render's default is the culled order (PTX_TRAVERSE_REFERENCE is 0 and cannot be told from "no flag");
+	 * both give the same image bit for bit, this one is the slow cross-check. */
+	PTX_RENDER_REFERENCE_ORDER = 1u << 10
 };
 
 /* ------------------------------------------------------------------ rays and hits */

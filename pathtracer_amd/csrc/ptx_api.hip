@@ -1044,6 +1044,8 @@ int ptx_trace_any(ptx_scene_t s, const PtxRay* rays, uint64_t n, uint8_t* occlud
 	} else if (s->rec.mesh_only) {
 		if (culled) hipLaunchKernelGGL((k_trace_any<MODE_CULLED, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
 		else hipLaunchKernelGGL((k_trace_any<MODE_REFERENCE, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
+	} else if (culled && scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && n < (uint64_t(1) << 32)) {
+		if (int rc = (launch_scene_persistent<BatchAnyIO, true>(s, BatchAnyIO{d_rays, n, d_occ}, n))) return rc;
 	} else {
 		if (culled) hipLaunchKernelGGL((k_trace_any<MODE_CULLED, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
 		else hipLaunchKernelGGL((k_trace_any<MODE_REFERENCE, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);

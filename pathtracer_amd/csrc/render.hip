@@ -74,6 +74,13 @@ struct RenderBuffers {
 	uint32_t* active[2];
 	uint32_t* counts;     // [0], [1]: sizes of active[0], active[1]
 	uint32_t n_slots, group;
+	// Scenes with point / spot / directional lights: per path and light, the shadow ray of sum_delta_lights
+	// (pathtracer.cpp:645-666), what it adds to the path's radiance when nothing blocks it (w: 1 when the light
+	// takes part at this vertex, else 0), and the occlusion query's answer.
+	PtxRay* shadow_rays;
+	float4* shadow_add;
+	uint8_t* shadow_occ;
+	uint32_t n_lights;
 };
 
 // Records move between registers and memory as whole 16-byte pieces (one vector load or store per
@@ -141,7 +148,7 @@ __device__ __forceinline__ void block_append(bool keep, uint32_t value, uint32_t
 }
 
 constexpr int RAYGEN_BLOCK = 1024;
-constexpr int shade_block(bool delta) { return delta ? 256 : 1024; }   // the variant walking shadow rays needs 206 VGPRs
+constexpr int SHADE_BLOCK = 1024;
 
 // Camera::sample_ray for samples k0 .. k0 + group - 1 of every slot that has them (pathtracer.cpp:448-454).
 __global__ void __launch_bounds__(RAYGEN_BLOCK) k_raygen(RenderBuffers rb, uint32_t k0, CameraRec cam, uint32_t key0, uint32_t key1,
@@ -258,10 +265,13 @@ __device__ __forceinline__ Surface rebuild_surface(const SceneRec& sc, const Sha
 }
 
 // The body of Pathtracer::trace for one active path, one recursion level per launch.
-// DELTA: the scene has point/spot/directional lights, whose shadow rays are walked in place; scenes
-// without them get an instance of the kernel free of the traversal's registers and stack.
-template<int MODE, bool DELTA>
-__global__ void __launch_bounds__(shade_block(DELTA)) k_shade(SceneRec sc, ShadeTables sh, RenderBuffers rb, const uint32_t* __restrict__ list,
+// DELTA: the scene has point/spot/directional lights.  Their shadow rays are not walked here: the kernel leaves,
+// per light, the shadow ray and what the light adds when unoccluded; an occlusion pass over all of them follows
+// (any-hit queries, the replenishing two-level kernel on large batches) and k_apply_shadows adds the unoccluded ones
+// to the path's radiance in light order -- the same additions in the same order as the reference's loop, since
+// nothing else touches the radiance between them and the next level's first addition.
+template<bool DELTA>
+__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables sh, RenderBuffers rb, const uint32_t* __restrict__ list,
                                                const uint32_t* __restrict__ count, uint32_t key0, uint32_t key1,
                                                uint32_t* __restrict__ next_list, uint32_t* __restrict__ next_count) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,6 +281,7 @@ __global__ void __launch_bounds__(shade_block(DELTA)) k_shade(SceneRec sc, Shade
 		slot = list[i];
 		PathState ps = load_rec(rb.paths + slot);
 		V3f T = v3(ps.T[0], ps.T[1], ps.T[2]), L = v3(ps.L[0], ps.L[1], ps.L[2]);
+		bool lights_written = false;
 
 		// ---- the direct ray traced last round: trace(rng, new_in_ray).first (pathtracer.cpp:71-76)
 		if (ps.flags & FLAG_HAS_DIRECT) {
@@ -322,19 +333,22 @@ __global__ void __launch_bounds__(shade_block(DELTA)) k_shade(SceneRec sc, Shade
 			const V3f emissive = bsdf_emission(sh, m, s.u, s.v);
 			if (camera) L = L + emissive;   // an indirect ray contributes `.second` only
 			if (ps.depth != 0 && m.type != PTX_MAT_EMISSIVE) {   // pathtracer.cpp:163
-				// sum_delta_lights (pathtracer.cpp:645-666)
+				// sum_delta_lights (pathtracer.cpp:645-666): shadow rays and contributions for the occlusion pass
 				if (DELTA && !mat_is_specular(m.type)) {
+					lights_written = true;
 					for (uint32_t li = 0; li < sh.n_delta_lights; li++) {
+						const size_t item = size_t(slot) * sh.n_delta_lights + li;
 						const IncomingRec inc = light_incoming(sh.delta_lights[li], s.position);
 						const V3f in_dir = f.to_local(inc.direction);
 						const V3f att = bsdf_evaluate(sh, m, in_dir, s.u, s.v);   // evaluate(out_dir, in_dir): cosine of in_dir
-						if (0.2126f * att.x + 0.7152f * att.y + 0.0722f * att.z == 0.0f) continue;
+						if (0.2126f * att.x + 0.7152f * att.y + 0.0722f * att.z == 0.0f) {
+							rb.shadow_add[item] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+							continue;
+						}
 						const V3f sd = unit(inc.direction);   // Ray's constructor
-						const Ray3 shadow{s.position.x, s.position.y, s.position.z, sd.x, sd.y, sd.z, SH_EPS, inc.distance - SH_EPS};
-						Stack st;
-						SceneHit occ;
-						traverse_scene<MODE, true>(sc, shadow, st, occ);
-						if (!occ.hit) L = L + T * (att * inc.radiance);
+						store_rec(rb.shadow_rays + item, PtxRay{{s.position.x, s.position.y, s.position.z}, {sd.x, sd.y, sd.z}, SH_EPS, inc.distance - SH_EPS});
+						const V3f add = T * (att * inc.radiance);
+						rb.shadow_add[item] = make_float4(add.x, add.y, add.z, 1.0f);
 					}
 				}
 				PathRng rng;
@@ -364,6 +378,8 @@ __global__ void __launch_bounds__(shade_block(DELTA)) k_shade(SceneRec sc, Shade
 				alive = true;
 			}
 		}
+		if (DELTA && !lights_written)   // no light takes part at this vertex: the occlusion pass skips the path's entries
+			for (uint32_t li = 0; li < sh.n_delta_lights; li++) rb.shadow_add[size_t(slot) * sh.n_delta_lights + li] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		if (alive) {
 			ps.T[0] = T.x, ps.T[1] = T.y, ps.T[2] = T.z, ps.L[0] = L.x, ps.L[1] = L.y, ps.L[2] = L.z;
 			store_rec(rb.paths + slot, ps);
@@ -371,7 +387,64 @@ __global__ void __launch_bounds__(shade_block(DELTA)) k_shade(SceneRec sc, Shade
 			rb.rad[slot] = make_float4(L.x, L.y, L.z, 0.0f);   // folded into the slot's sum in sample order by k_sum_pass
 		}
 	}
-	block_append<shade_block(DELTA) / 64>(alive, slot, next_list, next_count);
+	block_append<SHADE_BLOCK / 64>(alive, slot, next_list, next_count);
+}
+
+// The shadow rays k_shade left, as a ray source / answer sink of the occlusion kernels: item k is light k % n_lights
+// of the path list[k / n_lights]; entries whose light does not take part carry no ray.
+struct ShadowIO {
+	RenderBuffers rb;
+	const uint32_t* list;
+	const uint32_t* n_paths;
+	__device__ __forceinline__ uint64_t count() const { return uint64_t(*n_paths) * rb.n_lights; }
+	__device__ __forceinline__ void load(uint32_t out, Ray3& r) const {
+		const float4* rp = reinterpret_cast<const float4*>(rb.shadow_rays + out);
+		const float4 a = rp[0], b = rp[1];
+		r = Ray3{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	}
+	__device__ __forceinline__ bool fetch(uint64_t item, Ray3& r, uint32_t& out) const {
+		out = list[item / rb.n_lights] * rb.n_lights + uint32_t(item % rb.n_lights);
+		if (rb.shadow_add[out].w == 0.0f) return false;
+		load(out, r);
+		return true;
+	}
+	__device__ __forceinline__ void store(uint32_t out, const SceneHit& h) const { rb.shadow_occ[out] = h.hit ? 1 : 0; }
+};
+
+// Occlusion queries one ray per lane: small batches, scenes the replenishing kernel does not take, reference order.
+template<int MODE>
+__global__ void __launch_bounds__(256) k_shadow_plain(SceneRec sc, ShadowIO io) {
+	const uint64_t item = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (item >= io.count()) return;
+	Ray3 r;
+	uint32_t out;
+	if (!io.fetch(item, r, out)) return;
+	Stack st;
+	SceneHit h;
+	traverse_scene<MODE, true>(sc, r, st, h);
+	io.store(out, h);
+}
+
+// `if (!shadow.hit) radiance += attenuation * incoming.radiance` (pathtracer.cpp:660-662) for every light in order.
+// A path that had lights taking part is still alive (it scattered at the same vertex), so its radiance is in its state.
+__global__ void __launch_bounds__(256) k_apply_shadows(RenderBuffers rb, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= *count) return;
+	const uint32_t slot = list[i];
+	float Lx = 0.0f, Ly = 0.0f, Lz = 0.0f;
+	bool any = false;
+	for (uint32_t li = 0; li < rb.n_lights; li++) {
+		const size_t item = size_t(slot) * rb.n_lights + li;
+		const float4 add = rb.shadow_add[item];
+		if (add.w == 0.0f || rb.shadow_occ[item]) continue;
+		if (!any) {
+			const PathState& ps = rb.paths[slot];
+			Lx = ps.L[0], Ly = ps.L[1], Lz = ps.L[2];
+			any = true;
+		}
+		Lx += add.x, Ly += add.y, Lz += add.z;
+	}
+	if (any) rb.paths[slot].L[0] = Lx, rb.paths[slot].L[1] = Ly, rb.paths[slot].L[2] = Lz;
 }
 
 // The samples of one pass added to their slot's sum in sample order, so that the float sum per pixel is
@@ -487,7 +560,13 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		if (chunk.empty()) continue;
 		const uint32_t ns = uint32_t(n_slots);
 		// samples of a slot in flight together: as many as keep the paths within the state buffers' budget
-		const uint32_t group = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(max_samples, MAX_SLOTS_PER_CHUNK / n_slots)));
+		uint32_t group = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(max_samples, MAX_SLOTS_PER_CHUNK / n_slots)));
+		if (s->shade.n_delta_lights) {
+			// one shadow-ray record per path in flight and light: keep their number within 2^28 (13 GB) and their index in 32 bits
+			const uint64_t per_sample = n_slots * uint64_t(s->shade.n_delta_lights);
+			if (per_sample >= (uint64_t(1) << 32)) return fail(PTX_ERR_UNSUPPORTED, "ptx_render_tiles: tiles x delta lights exceed 2^32 shadow rays per sample; pass fewer tiles per call");
+			group = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(group, (uint64_t(1) << 28) / per_sample)));
+		}
 		const uint64_t n_paths = n_slots * group;
 		RenderBuffers rb{};
 		rb.n_slots = ns, rb.group = group;
@@ -495,7 +574,9 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		if (int rc = device_alloc(s, 2, chunk.size() * sizeof(TileRec), &p)) return rc;
 		TileRec* d_tiles = static_cast<TileRec*>(p);
 		// one allocation for all per-slot and per-path state
-		const size_t bytes = n_slots * (sizeof(SlotInfo) + sizeof(float4)) + n_paths * (sizeof(float4) + sizeof(PathState) + 2 * sizeof(PtxRay) + 2 * sizeof(HitRec) + 2 * sizeof(uint32_t)) + 256;
+		const uint32_t n_lights = s->shade.n_delta_lights;
+		const size_t shadow_bytes = size_t(n_lights) * (sizeof(PtxRay) + sizeof(float4) + 1) + 16;   // per path
+		const size_t bytes = n_slots * (sizeof(SlotInfo) + sizeof(float4)) + n_paths * (sizeof(float4) + sizeof(PathState) + 2 * sizeof(PtxRay) + 2 * sizeof(HitRec) + 2 * sizeof(uint32_t) + (n_lights ? shadow_bytes : 0)) + 256;
 		if (int rc = device_alloc(s, 3, bytes, &p)) return rc;
 		char* base = static_cast<char*>(p);
 		rb.counts = reinterpret_cast<uint32_t*>(base), base += 256;
@@ -506,7 +587,14 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		rb.sums = reinterpret_cast<float4*>(base), base += n_slots * sizeof(float4);
 		rb.slots = reinterpret_cast<SlotInfo*>(base), base += n_slots * sizeof(SlotInfo);
 		rb.active[0] = reinterpret_cast<uint32_t*>(base), base += n_paths * sizeof(uint32_t);
-		rb.active[1] = reinterpret_cast<uint32_t*>(base);
+		rb.active[1] = reinterpret_cast<uint32_t*>(base), base += n_paths * sizeof(uint32_t);
+		rb.n_lights = n_lights;
+		if (n_lights) {
+			base += (16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15;
+			rb.shadow_rays = reinterpret_cast<PtxRay*>(base), base += n_paths * n_lights * sizeof(PtxRay);
+			rb.shadow_add = reinterpret_cast<float4*>(base), base += n_paths * n_lights * sizeof(float4);
+			rb.shadow_occ = reinterpret_cast<uint8_t*>(base);
+		}
 		PTX_HIP(hipMemcpyAsync(d_tiles, chunk.data(), chunk.size() * sizeof(TileRec), hipMemcpyHostToDevice, s->stream));
 		hipLaunchKernelGGL(k_init_slots, dim3(uint32_t(chunk.size())), dim3(256), 0, s->stream, d_tiles, cam->film_width, rb);
 
@@ -514,7 +602,8 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		const dim3 block(256), grid_slots((ns + 255) / 256), grid_items((2 * n_paths + 255) / 256);
 		// Small batches (a 256x256 film is 65k paths, 8 waves per CU) do not fill the replenishing kernel's
 		// waves for long enough to pay for its set-up launches: they keep one ray per lane.
-		const bool persistent = scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && np >= (1u << 18);
+		const bool reference_order = (flags & PTX_RENDER_REFERENCE_ORDER) != 0;
+		const bool persistent = scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && !reference_order && np >= (1u << 18);
 		for (uint32_t k = 0; k < max_samples; k += group) {
 			PTX_HIP(hipMemsetAsync(rb.counts, 0, 256, s->stream));
 			hipLaunchKernelGGL(k_raygen, dim3((np + RAYGEN_BLOCK - 1) / RAYGEN_BLOCK), dim3(RAYGEN_BLOCK), 0, s->stream, rb, k, cr, key0, key1, rb.active[0], rb.counts + 0);
@@ -525,14 +614,29 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 			for (uint32_t round = 0; round <= cam->film_max_ray_depth; round++) {
 				if (persistent) {
 					if (int rc = launch_scene_persistent(s, RenderIO{rb, rb.active[cur], rb.counts + cur, round == 0 ? 1u : 2u}, 2 * n_paths)) return rc;
+				} else if (reference_order) {
+					hipLaunchKernelGGL(k_extend<MODE_REFERENCE>, grid_items, block, 0, s->stream, s->rec, rb, rb.active[cur], rb.counts + cur);
 				} else {
 					hipLaunchKernelGGL(k_extend<MODE_CULLED>, grid_items, block, 0, s->stream, s->rec, rb, rb.active[cur], rb.counts + cur);
 				}
 				PTX_HIP(hipMemsetAsync(rb.counts + (cur ^ 1), 0, sizeof(uint32_t), s->stream));
-				const bool delta = s->shade.n_delta_lights != 0;
-				const auto shade = delta ? k_shade<MODE_CULLED, true> : k_shade<MODE_CULLED, false>;
-				hipLaunchKernelGGL(shade, dim3((np + shade_block(delta) - 1) / shade_block(delta)), dim3(shade_block(delta)), 0, s->stream, s->rec, s->shade, rb, rb.active[cur], rb.counts + cur, key0, key1,
+				const bool delta = n_lights != 0;
+				const auto shade = delta ? k_shade<true> : k_shade<false>;
+				hipLaunchKernelGGL(shade, dim3((np + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->rec, s->shade, rb, rb.active[cur], rb.counts + cur, key0, key1,
 				                   rb.active[cur ^ 1], rb.counts + (cur ^ 1));
+				if (delta && round < cam->film_max_ray_depth) {   // the vertex of depth 0 gathers no light
+					// the occlusion pass over the shadow rays of the paths just shaded, then their contributions in light order
+					const ShadowIO sio{rb, rb.active[cur], rb.counts + cur};
+					const uint64_t max_items = n_paths * n_lights;
+					if (persistent) {
+						if (int rc = (launch_scene_persistent<ShadowIO, true>(s, sio, max_items))) return rc;
+					} else {
+						const dim3 grid_shadow(uint32_t((max_items + 255) / 256));
+						if (reference_order) hipLaunchKernelGGL(k_shadow_plain<MODE_REFERENCE>, grid_shadow, block, 0, s->stream, s->rec, sio);
+						else hipLaunchKernelGGL(k_shadow_plain<MODE_CULLED>, grid_shadow, block, 0, s->stream, s->rec, sio);
+					}
+					hipLaunchKernelGGL(k_apply_shadows, dim3((np + 255) / 256), block, 0, s->stream, rb, rb.active[cur], rb.counts + cur);
+				}
 				cur ^= 1;
 			}
 			hipLaunchKernelGGL(k_sum_pass, grid_slots, block, 0, s->stream, rb, k);

@@ -64,11 +64,31 @@ struct BatchIO {   // ptx_trace_closest on a general scene
 	}
 };
 
+struct BatchAnyIO {   // ptx_trace_any on a general scene: `scene.hit(shadow_ray).hit` (pathtracer.cpp:657-660)
+	const PtxRay* rays;
+	uint64_t n;
+	uint8_t* occluded;
+	__device__ __forceinline__ uint64_t count() const { return n; }
+	__device__ __forceinline__ void load(uint32_t out, Ray3& r) const {
+		const float4* rp = reinterpret_cast<const float4*>(rays + out);
+		const float4 a = rp[0], b = rp[1];
+		r = Ray3{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	}
+	__device__ __forceinline__ bool fetch(uint64_t item, Ray3& r, uint32_t& out) const {
+		out = uint32_t(item);
+		load(out, r);
+		return true;
+	}
+	__device__ __forceinline__ void store(uint32_t out, const SceneHit& h) const { occluded[out] = h.hit ? 1 : 0; }
+};
+
 // Registers, not LDS, decide how many waves share a SIMD here.  With the world ray (while the lane is
 // inside an instance) and the once-per-ray bookkeeping kept in LDS the kernel fits 96 VGPRs without
 // spilling: five waves per SIMD, five 31 KB blocks per CU.  (At the 117 VGPRs of the all-in-registers
 // version only four fit; the same render took 11 % longer.)
-template<typename IO>
+// ANY: occlusion queries.  A ray is finished by the first primitive it hits inside its distance bounds, subtrees
+// are skipped against the ray's far bound instead of a running closest hit, and only the hit flag is stored.
+template<typename IO, bool ANY = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_scene_persistent(SceneRec sc, IO io, unsigned long long* __restrict__ next_item, uint32_t* __restrict__ slow_list,
                                                           uint32_t* __restrict__ slow_count, const int refill_min, const unsigned long long wave_chunk, const int walk_steps) {
 	constexpr int MODE = MODE_CULLED;
@@ -110,7 +130,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 	// At the top level a leaf reference names the instance to visit next (its first) and how many of the
 	// leaf's instances are left, that one included.  Empty leaves are skipped.
 	auto settle_top = [&]() {
-		while ((ref & REF_LEAF) && ref != REF_DONE && (ref & 15u) == 0u) pop_ref<MODE, false>(cr, st, 0, sp, ref, best_hit, best_distance);
+		while ((ref & REF_LEAF) && ref != REF_DONE && (ref & 15u) == 0u) pop_ref<MODE, ANY>(cr, st, 0, sp, ref, best_hit, best_distance);
 	};
 	// The next instance of the top-level leaf `leaf`, or the next pending top-level subtree.
 	auto next_top = [&](uint32_t leaf) {
@@ -123,7 +143,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 		if ((leaf & 15u) > 1u) {
 			ref = leaf + 15u;   // first + 1, count - 1: ENTER again, for the leaf's next instance
 		} else {
-			pop_ref<MODE, false>(cr, st, 0, sp, ref, best_hit, best_distance);
+			pop_ref<MODE, ANY>(cr, st, 0, sp, ref, best_hit, best_distance);
 			settle_top();
 		}
 	};
@@ -197,7 +217,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 		// pending subtree (empty leaves are dropped on the way)
 		while (have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE && pend == 0u) {
 			if (ref & 15u) pend = ref;
-			pop_ref<MODE, false>(cr, st, base, sp, ref, mh.hit, mh.distance);
+			pop_ref<MODE, ANY>(cr, st, base, sp, ref, mh.hit, mh.distance);
 		}
 		const bool can_walk = have_ray && !(ref & REF_LEAF);
 		const bool has_parked = have_ray && pend != 0u;
@@ -224,7 +244,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 				if (have_ray && !(ref & REF_LEAF)) {
 					const bool run_hit = level ? mh.hit : best_hit;
 					const float run_dist = level ? mh.distance : best_distance;
-					node_step<MODE, false, true, false>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
+					node_step<MODE, ANY, true, false>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
 					if (level == 0u) settle_top();
 				}
 			}
@@ -234,8 +254,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 			prof[3]++, prof[4] += n_tri;
 #endif
 			if (has_parked) {
-				mesh_leaf<MODE, false, false>(sc.tris + ctri_base, (pend & REF_INDEX_MASK) >> 4, pend & 15u, cr, mh, nullptr);
+				mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (pend & REF_INDEX_MASK) >> 4, pend & 15u, cr, mh, nullptr);
 				pend = 0u;
+				if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
 			}
 		} else if (n_exit == n_max) {
 			// ---- leave an instance: Instance::hit's tail (instance.h:36-39): Trace::transform(T, iT.T())
@@ -247,14 +268,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 				const uint32_t leaf = ledger[L_TOP_LEAF], cur_inst = (leaf & REF_INDEX_MASK) >> 4;
 				const InstRec& in = sc.insts[cur_inst];
 				float dist = mh.distance;
-				if (mh.hit && in.has_transform) {
+				if (!ANY && mh.hit && in.has_transform) {
 					const float px = cr.ox + cr.dx * mh.t, py = cr.oy + cr.dy * mh.t, pz = cr.oz + cr.dz * mh.t;
 					float wx, wy, wz, qx, qy, qz;
 					mat_point(in.T, px, py, pz, wx, wy, wz);
 					mat_point(in.T, cr.ox, cr.oy, cr.oz, qx, qy, qz);
 					dist = norm3(wx - qx, wy - qy, wz - qz);
 				}
-				fold_world(cur_inst, mh.hit, dist, mh.t, mh.prim, mh.u, mh.v);
+				if (!ANY) fold_world(cur_inst, mh.hit, dist, mh.t, mh.prim, mh.u, mh.v);   // ANY: a lane gets here only without a hit
 				next_top(leaf);
 			}
 		} else {
@@ -272,15 +293,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 					float t;
 					const bool hit = sphere_test(in.radius, r, t);
 					float dist = t;
-					if (hit && in.has_transform) {
+					if (!ANY && hit && in.has_transform) {
 						const float px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
 						float wx, wy, wz, qx, qy, qz;
 						mat_point(in.T, px, py, pz, wx, wy, wz);
 						mat_point(in.T, r.ox, r.oy, r.oz, qx, qy, qz);
 						dist = norm3(wx - qx, wy - qy, wz - qz);
 					}
-					fold_world(cur_inst, hit, dist, t, 0u, 0.0f, 0.0f);
-					next_top(leaf);
+					if (ANY && hit) {
+						best_hit = true, ref = REF_DONE, sp = 0;
+					} else {
+						fold_world(cur_inst, hit, dist, t, 0u, 0.0f, 0.0f);
+						next_top(leaf);
+					}
 				} else {
 					const MeshRec& mesh = sc.meshes[in.mesh];
 					if (mesh.is_list || !mesh.tame || !ray_in_fast_range(r)) {
@@ -325,7 +350,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 }
 
 // The rays k_scene_persistent set aside: one ray per lane, plain divisions, any scene.
-template<typename IO>
+template<typename IO, bool ANY = false>
 __global__ void __launch_bounds__(256) k_scene_deferred(SceneRec sc, IO io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count) {
 	const uint32_t n = *count;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
@@ -334,8 +359,8 @@ __global__ void __launch_bounds__(256) k_scene_deferred(SceneRec sc, IO io, cons
 		io.load(out, r);
 		Stack st;
 		SceneHit h;
-		traverse_scene<MODE_CULLED, false>(sc, r, st, h);
-		if (needs_reference_order(r, h.hit, h.distance)) traverse_scene<MODE_REFERENCE, false>(sc, r, st, h);
+		traverse_scene<MODE_CULLED, ANY>(sc, r, st, h);
+		if (!ANY && needs_reference_order(r, h.hit, h.distance)) traverse_scene<MODE_REFERENCE, false>(sc, r, st, h);
 		io.store(out, h);
 	}
 }
@@ -345,7 +370,7 @@ __global__ void __launch_bounds__(256) k_scene_deferred(SceneRec sc, IO io, cons
 // exactly (lists, untamed trees) send their rays to k_scene_deferred one by one.
 inline bool scene_persistent_ok(const PtxScene* s) { return !s->rec.mesh_only && !s->rec.top_is_list && s->rec.top_tame && s->rec.n_insts > 0; }
 
-template<typename IO>
+template<typename IO, bool ANY = false>
 int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 	unsigned long long* counters = nullptr;
 	if (int rc = scene_counter_block(s, &counters)) return rc;
@@ -360,7 +385,7 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 	static const int walk_steps = getenv("PTX_SCENE_WALK_STEPS") ? std::max(1, atoi(getenv("PTX_SCENE_WALK_STEPS"))) : SCENE_WALK_STEPS;
 	const uint64_t want = (max_items + 255) / 256;
 	const dim3 block(256), grid(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu))))));
-	hipLaunchKernelGGL((k_scene_persistent<IO>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count, refill_min, wave_chunk, walk_steps);
+	hipLaunchKernelGGL((k_scene_persistent<IO, ANY>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count, refill_min, wave_chunk, walk_steps);
 #ifdef PTX_PROFILE_LANES
 	{
 		static unsigned long long tot[9] = {};
@@ -375,7 +400,7 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 			             double(tot[8]) / double(tot[7] ? tot[7] : 1));
 	}
 #endif
-	hipLaunchKernelGGL((k_scene_deferred<IO>), dim3(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, 256)))), block, 0, s->stream, s->rec, io, slow_list, slow_count);
+	hipLaunchKernelGGL((k_scene_deferred<IO, ANY>), dim3(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, 256)))), block, 0, s->stream, s->rec, io, slow_list, slow_count);
 	return PTX_OK;
 }
 

@@ -214,3 +214,21 @@ def test_large_batch_replenishing_extend_is_bit_identical(oracle):
     osc.close()
     # at 2 spp one sample that took another path (a last-bit difference in sin/cos/pow) moves its pixel by O(1): wider RMSE bound
     assert_same_stream(capi.accumulator_to_image(acc_o, smp_o), capi.accumulator_to_image(acc_p, smp_p), rmse_rel=1e-2)
+
+
+@pytest.mark.parametrize("w,spp", [(96, 4), (512, 2)])
+def test_render_reference_order_flag_is_bit_identical(w, spp):
+    """PTX_RENDER_REFERENCE_ORDER walks every extend and shadow ray of the render in the reference's visit order
+    (bvh.cpp:246-375: left subtree first, no distance culling).  The default culled order must give the very same
+    accumulator, on the one-ray-per-lane kernels (small film) and on the replenishing ones (>= 2^18 paths),
+    in a scene whose delta lights send shadow rays through the occlusion pass."""
+    sb = lit_scene("delta")
+    cam = camera(w, w, spp, 5)
+    tiles = capi.make_tiles(w, w, spp, 9)
+    gsc = capi.Scene(sb.desc(), keep=sb)
+    acc_c, smp_c = gsc.render_tiles(cam, tiles, SEED)
+    acc_r, smp_r = gsc.render_tiles(cam, tiles, SEED, flags=abi.PTX_RENDER_REFERENCE_ORDER)
+    gsc.close()
+    assert (smp_c == spp).all() and (smp_r == spp).all()
+    assert acc_c.any()
+    assert (acc_c == acc_r).all(), f"{int((acc_c != acc_r).sum())} accumulator words differ between the two orders"

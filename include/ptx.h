@@ -68,7 +68,15 @@ enum {
 	/* ptx_render_tiles only: walk every ray of the render (extend and shadow rays) in the reference's visit order.
 	 * The render's default is the culled order (PTX_TRAVERSE_REFERENCE is 0 and cannot be told from "no flag");
 	 * both give the same image bit for bit, this one is the slow cross-check. */
-	PTX_RENDER_REFERENCE_ORDER = 1u << 10
+	PTX_RENDER_REFERENCE_ORDER = 1u << 10,
+	/* ptx_render_tiles only: also trace the rays whose answer cannot reach the image.  By default two kinds are
+	 * left out, with the same accumulator bit for bit: (1) the scattered ray of a path's last vertex -- its ray has
+	 * depth 0, and sample_indirect_lighting uses only `.second` of trace(), which is {} at depth 0
+	 * (pathtracer.cpp:118,163); (2) in scenes without environment lights and with few, small Emissive instances,
+	 * a direct-lighting ray (pathtracer.cpp:64-71: depth 0, only the emission of its first hit is used) that
+	 * touches no primitive of an Emissive instance, when the weight it would be multiplied by is finite.
+	 * This flag is the cross-check. */
+	PTX_RENDER_TRACE_UNUSED_RAYS = 1u << 11
 };
 
 /* ------------------------------------------------------------------ rays and hits */

@@ -16,6 +16,7 @@ PTX_TRAVERSE_CULLED = 1 << 4
 PTX_NO_PERSISTENT = 1 << 8
 PTX_RAYS_COHERENT = 1 << 9
 PTX_RENDER_REFERENCE_ORDER = 1 << 10
+PTX_RENDER_TRACE_UNUSED_RAYS = 1 << 11
 
 PTX_MAT_LAMBERTIAN, PTX_MAT_MIRROR, PTX_MAT_REFRACT, PTX_MAT_GLASS, PTX_MAT_EMISSIVE = range(5)
 PTX_TEX_CONSTANT, PTX_TEX_IMAGE = range(2)

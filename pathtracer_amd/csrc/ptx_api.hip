@@ -873,6 +873,19 @@ int ptx_scene_create(int device, const PtxSceneDesc* d, ptx_scene_t* out) {
 	s->shade.n_delta_lights = uint32_t(dls.size());
 	s->shade.n_env_lights = uint32_t(els.size());
 	s->shade.fresnel_mode = d->fresnel_mode;
+	{
+		// Instances whose material can emit (bsdf->emission() is zero for every other material, material.cpp).
+		uint32_t n = 0, prims = 0;
+		bool fits = true;
+		for (uint32_t i = 0; i < d->n_instances && fits; i++) {
+			if (mats[size_t(insts[i].material)].type != PTX_MAT_EMISSIVE) continue;
+			prims += insts[i].mesh >= 0 ? d->meshes[insts[i].mesh].n_tris : 1u;
+			if (n == MAX_EMISSIVE_INSTS || prims > MAX_EMISSIVE_PRIMS) fits = false;
+			else s->shade.emissive_insts[n++] = i;
+		}
+		s->shade.n_emissive = fits ? n : 0;
+		s->shade.direct_skip = (fits && els.empty()) ? 1 : 0;
+	}
 	*out = s;
 	return PTX_OK;
 }

@@ -72,7 +72,8 @@ struct RenderBuffers {
 	PtxRay* rays;         // 2 per path: main, direct
 	HitRec* hits;         // 2 per path
 	uint32_t* active[2];
-	uint32_t* counts;     // [0], [1]: sizes of active[0], active[1]
+	uint32_t* direct;     // the paths of the next active list whose direct ray is to be traced
+	uint32_t* counts;     // [0], [1]: sizes of active[0], active[1]; [2]: size of direct
 	uint32_t n_slots, group;
 	// Scenes with point / spot / directional lights: per path and light, the shadow ray of sum_delta_lights
 	// (pathtracer.cpp:645-666), what it adds to the path's radiance when nothing blocks it (w: 1 when the light
@@ -178,43 +179,23 @@ __global__ void __launch_bounds__(RAYGEN_BLOCK) k_raygen(RenderBuffers rb, uint3
 	block_append<RAYGEN_BLOCK / 64>(live, path, out_list, out_count);
 }
 
-// Closest hit for the main ray of every active path and for its direct ray when it has one.
-template<int MODE>
-__global__ void __launch_bounds__(256) k_extend(SceneRec sc, RenderBuffers rb, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count) {
-	const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
-	if ((item >> 1) >= *count) return;
-	const uint32_t slot = list[item >> 1], which = item & 1u;
-	if (which == 1u && !(rb.paths[slot].flags & FLAG_HAS_DIRECT)) return;
-	const float4* rp = reinterpret_cast<const float4*>(rb.rays + 2 * slot + which);
-	const float4 a = rp[0], b = rp[1];
-	Ray3 r{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-	Stack st;
-	SceneHit h;
-	traverse_scene<MODE, false>(sc, r, st, h);
-	if (MODE == MODE_CULLED && needs_reference_order(r, h.hit, h.distance)) traverse_scene<MODE_REFERENCE, false>(sc, r, st, h);
-	HitRec out{};
-	out.distance = h.distance, out.t = h.t, out.u = h.u, out.v = h.v;
-	out.prim = h.hit ? h.prim : 0xFFFFFFFFu, out.inst = h.inst;
-	store_rec(rb.hits + 2 * slot + which, out);
-}
-
-// The same work as k_extend as a ray source / hit sink of k_scene_persistent: the main rays of
-// the active paths first (neighbouring pixels, the more coherent half), then their direct rays.
+// The rays of one extend round as a ray source / hit sink of the traversal kernels: the main rays of the active
+// paths first (neighbouring pixels, the more coherent half), then the direct rays k_shade asked for.
 struct RenderIO {
 	RenderBuffers rb;
 	const uint32_t* list;
 	const uint32_t* n_paths;
-	uint32_t rays_per_path;   // 1 right after raygen (camera rays only), else 2
-	__device__ __forceinline__ uint64_t count() const { return uint64_t(*n_paths) * rays_per_path; }
+	uint32_t main_rays;       // 0: the main rays are not traced this round (nothing would use their hits)
+	__device__ __forceinline__ uint32_t n_main() const { return main_rays ? *n_paths : 0u; }
+	__device__ __forceinline__ uint64_t count() const { return uint64_t(n_main()) + rb.counts[2]; }
 	__device__ __forceinline__ void load(uint32_t out, Ray3& r) const {
 		const float4* rp = reinterpret_cast<const float4*>(rb.rays + out);
 		const float4 a = rp[0], b = rp[1];
 		r = Ray3{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 	}
 	__device__ __forceinline__ bool fetch(uint64_t item, Ray3& r, uint32_t& out) const {
-		const uint32_t n = *n_paths;
-		const uint32_t which = item >= n ? 1u : 0u;
-		out = 2u * list[which ? item - n : item] + which;
+		const uint32_t n = n_main();
+		out = item < n ? 2u * list[item] : 2u * rb.direct[item - n] + 1u;
 		load(out, r);
 		return true;
 	}
@@ -225,6 +206,45 @@ struct RenderIO {
 		store_rec(rb.hits + out, o);
 	}
 };
+
+// Closest hits one ray per lane: small batches, scenes the replenishing kernel does not take, reference order.
+template<int MODE>
+__global__ void __launch_bounds__(256) k_extend(SceneRec sc, RenderIO io) {
+	const uint64_t item = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (item >= io.count()) return;
+	Ray3 r;
+	uint32_t out;
+	io.fetch(item, r, out);
+	Stack st;
+	SceneHit h;
+	traverse_scene<MODE, false>(sc, r, st, h);
+	if (MODE == MODE_CULLED && needs_reference_order(r, h.hit, h.distance)) traverse_scene<MODE_REFERENCE, false>(sc, r, st, h);
+	io.store(out, h);
+}
+
+// Whether a direct-lighting ray can bring back light at all: it touches a primitive of an Emissive instance.
+// The traversal proper would run these very tests (same object-space ray, same functions) on the primitives whose
+// boxes the ray passes, so a hit it finds on an Emissive instance is found here too; a ray for which this returns
+// false ends, in the reference, on a surface whose emission is zero or on nothing (pathtracer.cpp:129-163).
+__device__ __forceinline__ bool direct_ray_may_see_light(const SceneRec& sc, const ShadeTables& sh, const Ray3& world) {
+	for (uint32_t e = 0; e < sh.n_emissive; e++) {
+		const InstRec& in = sc.insts[sh.emissive_insts[e]];
+		Ray3 r = world;
+		if (in.has_transform) r = ray_transform(in.iT, world);
+		if (in.mesh < 0) {
+			float t;
+			if (sphere_test(in.radius, r, t)) return true;
+		} else {
+			const MeshRec& mesh = sc.meshes[in.mesh];
+			const float4* p = reinterpret_cast<const float4*>(sc.tris + mesh.tri_base);
+			for (uint32_t k = 0; k < mesh.n_tris; k++) {
+				float d, t, u, v;
+				if (triangle_test(p[3 * k], p[3 * k + 1], p[3 * k + 2], r, d, t, u, v)) return true;
+			}
+		}
+	}
+	return false;
+}
 
 // What Pathtracer::trace needs of a Trace (trace.h:20-26) rebuilt from a HitRec.
 struct Surface {
@@ -275,7 +295,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
                                                const uint32_t* __restrict__ count, uint32_t key0, uint32_t key1,
                                                uint32_t* __restrict__ next_list, uint32_t* __restrict__ next_count) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	bool alive = false;
+	bool alive = false, wants_direct = false;
 	uint32_t slot = 0;
 	if (i < *count) {
 		slot = list[i];
@@ -320,7 +340,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 		const V3f ray_o = v3(mr.o[0], mr.o[1], mr.o[2]), ray_d = v3(mr.d[0], mr.d[1], mr.d[2]);
 		const bool camera = ps.flags & FLAG_CAMERA;
 		ps.flags = 0;
-		if (mh.prim == 0xFFFFFFFFu || sc.insts[mh.inst].material < 0) {
+		if (!camera && ps.depth == 0) {
+			// the scattered ray of the path's last vertex: trace() would return {emissive, {}} for it and
+			// sample_indirect_lighting uses `.second` only (pathtracer.cpp:118,163); it may not even have been traced
+		} else if (mh.prim == 0xFFFFFFFFu || sc.insts[mh.inst].material < 0) {
 			// miss: {env, {}} -- only a camera ray's (or a direct ray's) `.first` is ever used
 			if (camera && mh.prim == 0xFFFFFFFFu) L = L + env_radiance(sh, ray_d);
 		} else {
@@ -360,9 +383,16 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 					V3f w = sc1.specular ? sc1.attenuation : bsdf_evaluate(sh, m, out_dir, s.u, s.v);   // evaluate(in_dir, out_dir): `in` = out_dir
 					if (!sc1.specular) w = w / bsdf_pdf(m, out_dir);                                      // pdf(in_dir, out_dir): `in` = out_dir
 					const V3f Wd = T * w;
-					ps.Wd[0] = Wd.x, ps.Wd[1] = Wd.y, ps.Wd[2] = Wd.z;
-					store_rec(rb.rays + 2 * slot + 1, PtxRay{{s.position.x, s.position.y, s.position.z}, {in_world.x, in_world.y, in_world.z}, RAY_MINIMUM_BOUND, INFINITY});
-					ps.flags |= FLAG_HAS_DIRECT;
+					// The ray brings back `first`, the emission of the first surface it meets; the path gains first * Wd.
+					// Where first is provably zero and Wd finite that is +-0, and L + (+-0) == L: the ray is left out.
+					wants_direct = true;
+					if (sh.direct_skip && finite3(Wd))
+						wants_direct = direct_ray_may_see_light(sc, sh, Ray3{s.position.x, s.position.y, s.position.z, in_world.x, in_world.y, in_world.z, RAY_MINIMUM_BOUND, INFINITY});
+					if (wants_direct) {
+						ps.Wd[0] = Wd.x, ps.Wd[1] = Wd.y, ps.Wd[2] = Wd.z;
+						store_rec(rb.rays + 2 * slot + 1, PtxRay{{s.position.x, s.position.y, s.position.z}, {in_world.x, in_world.y, in_world.z}, RAY_MINIMUM_BOUND, INFINITY});
+						ps.flags |= FLAG_HAS_DIRECT;
+					}
 				}
 				// sample_indirect_lighting (pathtracer.cpp:81-124)
 				{
@@ -388,6 +418,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 		}
 	}
 	block_append<SHADE_BLOCK / 64>(alive, slot, next_list, next_count);
+	block_append<SHADE_BLOCK / 64>(wants_direct, slot, rb.direct, rb.counts + 2);
 }
 
 // The shadow rays k_shade left, as a ray source / answer sink of the occlusion kernels: item k is light k % n_lights
@@ -576,7 +607,7 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		// one allocation for all per-slot and per-path state
 		const uint32_t n_lights = s->shade.n_delta_lights;
 		const size_t shadow_bytes = size_t(n_lights) * (sizeof(PtxRay) + sizeof(float4) + 1) + 16;   // per path
-		const size_t bytes = n_slots * (sizeof(SlotInfo) + sizeof(float4)) + n_paths * (sizeof(float4) + sizeof(PathState) + 2 * sizeof(PtxRay) + 2 * sizeof(HitRec) + 2 * sizeof(uint32_t) + (n_lights ? shadow_bytes : 0)) + 256;
+		const size_t bytes = n_slots * (sizeof(SlotInfo) + sizeof(float4)) + n_paths * (sizeof(float4) + sizeof(PathState) + 2 * sizeof(PtxRay) + 2 * sizeof(HitRec) + 3 * sizeof(uint32_t) + (n_lights ? shadow_bytes : 0)) + 256;
 		if (int rc = device_alloc(s, 3, bytes, &p)) return rc;
 		char* base = static_cast<char*>(p);
 		rb.counts = reinterpret_cast<uint32_t*>(base), base += 256;
@@ -588,6 +619,7 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		rb.slots = reinterpret_cast<SlotInfo*>(base), base += n_slots * sizeof(SlotInfo);
 		rb.active[0] = reinterpret_cast<uint32_t*>(base), base += n_paths * sizeof(uint32_t);
 		rb.active[1] = reinterpret_cast<uint32_t*>(base), base += n_paths * sizeof(uint32_t);
+		rb.direct = reinterpret_cast<uint32_t*>(base), base += n_paths * sizeof(uint32_t);
 		rb.n_lights = n_lights;
 		if (n_lights) {
 			base += (16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15;
@@ -603,6 +635,9 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		// Small batches (a 256x256 film is 65k paths, 8 waves per CU) do not fill the replenishing kernel's
 		// waves for long enough to pay for its set-up launches: they keep one ray per lane.
 		const bool reference_order = (flags & PTX_RENDER_REFERENCE_ORDER) != 0;
+		const bool trace_unused = (flags & PTX_RENDER_TRACE_UNUSED_RAYS) != 0;
+		ShadeTables shade_tables = s->shade;
+		if (trace_unused) shade_tables.direct_skip = 0;
 		const bool persistent = scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && !reference_order && np >= (1u << 18);
 		for (uint32_t k = 0; k < max_samples; k += group) {
 			PTX_HIP(hipMemsetAsync(rb.counts, 0, 256, s->stream));
@@ -612,17 +647,22 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 			// vertex of depth 0 never scatters, so after D+1 rounds no path is alive and every
 			// direct ray (written in round r, used at the start of round r+1) has been consumed.
 			for (uint32_t round = 0; round <= cam->film_max_ray_depth; round++) {
+				// In the last round every main ray is the scattered ray of a path's last vertex (depth 0, not a camera
+				// ray): no hit of theirs is used, only the direct rays are traced.
+				const bool last_vertex_round = round == cam->film_max_ray_depth && round > 0;
+				const RenderIO io{rb, rb.active[cur], rb.counts + cur, (last_vertex_round && !trace_unused) ? 0u : 1u};
 				if (persistent) {
-					if (int rc = launch_scene_persistent(s, RenderIO{rb, rb.active[cur], rb.counts + cur, round == 0 ? 1u : 2u}, 2 * n_paths)) return rc;
+					if (int rc = launch_scene_persistent(s, io, 2 * n_paths)) return rc;
 				} else if (reference_order) {
-					hipLaunchKernelGGL(k_extend<MODE_REFERENCE>, grid_items, block, 0, s->stream, s->rec, rb, rb.active[cur], rb.counts + cur);
+					hipLaunchKernelGGL(k_extend<MODE_REFERENCE>, grid_items, block, 0, s->stream, s->rec, io);
 				} else {
-					hipLaunchKernelGGL(k_extend<MODE_CULLED>, grid_items, block, 0, s->stream, s->rec, rb, rb.active[cur], rb.counts + cur);
+					hipLaunchKernelGGL(k_extend<MODE_CULLED>, grid_items, block, 0, s->stream, s->rec, io);
 				}
 				PTX_HIP(hipMemsetAsync(rb.counts + (cur ^ 1), 0, sizeof(uint32_t), s->stream));
+				PTX_HIP(hipMemsetAsync(rb.counts + 2, 0, sizeof(uint32_t), s->stream));   // the direct rays just traced are consumed; k_shade lists the next ones
 				const bool delta = n_lights != 0;
 				const auto shade = delta ? k_shade<true> : k_shade<false>;
-				hipLaunchKernelGGL(shade, dim3((np + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->rec, s->shade, rb, rb.active[cur], rb.counts + cur, key0, key1,
+				hipLaunchKernelGGL(shade, dim3((np + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->rec, shade_tables, rb, rb.active[cur], rb.counts + cur, key0, key1,
 				                   rb.active[cur ^ 1], rb.counts + (cur ^ 1));
 				if (delta && round < cam->film_max_ray_depth) {   // the vertex of depth 0 gathers no light
 					// the occlusion pass over the shadow rays of the paths just shaded, then their contributions in light order

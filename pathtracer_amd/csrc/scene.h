@@ -43,6 +43,8 @@ struct EnvLightRec {
 	int32_t tex;
 };
 
+constexpr uint32_t MAX_EMISSIVE_INSTS = 8, MAX_EMISSIVE_PRIMS = 32;
+
 struct ShadeTables {
 	const TriAttr* attrs;
 	const TexRec* textures;
@@ -50,7 +52,13 @@ struct ShadeTables {
 	const MatRec* materials;
 	const DeltaLightRec* delta_lights;
 	const EnvLightRec* env_lights;
-	uint32_t n_delta_lights, n_env_lights, fresnel_mode, pad;
+	uint32_t n_delta_lights, n_env_lights, fresnel_mode;
+	// A direct-lighting ray (depth 0, pathtracer.cpp:64-71) brings back the emission of the first surface it meets and
+	// nothing else.  When the scene has no environment light and its Emissive instances are few and small, a ray
+	// that touches none of their primitives provably brings back zero and is not traced (render.hip, direct_ray_may_see_light).
+	uint32_t direct_skip;                          // 1: the list below is complete and usable
+	uint32_t n_emissive;
+	uint32_t emissive_insts[MAX_EMISSIVE_INSTS];   // positions in SceneRec::insts
 };
 
 }  // namespace ptx

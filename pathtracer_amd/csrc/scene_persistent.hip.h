@@ -161,6 +161,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 		}
 	};
 
+	// Instance::hit's tail (instance.h:36-39) for a lane whose walk of the current instance's mesh is finished:
+	// Trace::transform(T, iT.T()) recomputes the distance from the transformed hit point and origin (trace.h:38-43).
+	auto leave_instance = [&]() {
+		const uint32_t leaf = ledger[L_TOP_LEAF], cur_inst = (leaf & REF_INDEX_MASK) >> 4;
+		const InstRec& in = sc.insts[cur_inst];
+		float dist = mh.distance;
+		if (!ANY && mh.hit && in.has_transform) {
+			const float px = cr.ox + cr.dx * mh.t, py = cr.oy + cr.dy * mh.t, pz = cr.oz + cr.dz * mh.t;
+			float wx, wy, wz, qx, qy, qz;
+			mat_point(in.T, px, py, pz, wx, wy, wz);
+			mat_point(in.T, cr.ox, cr.oy, cr.oz, qx, qy, qz);
+			dist = norm3(wx - qx, wy - qy, wz - qz);
+		}
+		if (!ANY) fold_world(cur_inst, mh.hit, dist, mh.t, mh.prim, mh.u, mh.v);   // ANY: a lane gets here only without a hit
+		next_top(leaf);
+	};
+
 	// Exit condition every wave reaches: the pool runs dry and its lanes finish.  As a backstop against
 	// a scheduling mistake, a wave that has looped far longer than any workload needs hands its rays in
 	// flight, and whatever it still claims, to the plain kernel instead of walking them.
@@ -264,20 +281,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 #ifdef PTX_PROFILE_LANES
 			prof[5]++, prof[6] += n_exit;
 #endif
-			if (want_exit) {
-				const uint32_t leaf = ledger[L_TOP_LEAF], cur_inst = (leaf & REF_INDEX_MASK) >> 4;
-				const InstRec& in = sc.insts[cur_inst];
-				float dist = mh.distance;
-				if (!ANY && mh.hit && in.has_transform) {
-					const float px = cr.ox + cr.dx * mh.t, py = cr.oy + cr.dy * mh.t, pz = cr.oz + cr.dz * mh.t;
-					float wx, wy, wz, qx, qy, qz;
-					mat_point(in.T, px, py, pz, wx, wy, wz);
-					mat_point(in.T, cr.ox, cr.oy, cr.oz, qx, qy, qz);
-					dist = norm3(wx - qx, wy - qy, wz - qz);
-				}
-				if (!ANY) fold_world(cur_inst, mh.hit, dist, mh.t, mh.prim, mh.u, mh.v);   // ANY: a lane gets here only without a hit
-				next_top(leaf);
-			}
+			if (want_exit) leave_instance();
 		} else {
 			// ---- enter an instance (instance.h:32-35): ray to object space, then the sphere test or the
 			// mesh's root box
@@ -394,7 +398,8 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 		PTX_HIP(hipStreamSynchronize(s->stream));
 		PTX_HIP(hipMemcpy(h, counters, sizeof(h), hipMemcpyDeviceToHost));
 		for (int k = 0; k < 9; k++) tot[k] += h[16 + k];
-		if (++launches % 200 == 0)
+		static const int every = getenv("PTX_PROFILE_EVERY") ? std::max(1, atoi(getenv("PTX_PROFILE_EVERY"))) : 200;
+		if (++launches % every == 0)
 			std::fprintf(stderr, "[scene lanes] iterations %llu | walk %llu x %.1f | tri %llu x %.1f | exit %llu x %.1f | enter %llu x %.1f\n", tot[0], tot[1],
 			             double(tot[2]) / double(tot[1] ? tot[1] : 1), tot[3], double(tot[4]) / double(tot[3] ? tot[3] : 1), tot[5], double(tot[6]) / double(tot[5] ? tot[5] : 1), tot[7],
 			             double(tot[8]) / double(tot[7] ? tot[7] : 1));

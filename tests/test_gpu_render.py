@@ -232,3 +232,71 @@ def test_render_reference_order_flag_is_bit_identical(w, spp):
     assert (smp_c == spp).all() and (smp_r == spp).all()
     assert acc_c.any()
     assert (acc_c == acc_r).all(), f"{int((acc_c != acc_r).sum())} accumulator words differ between the two orders"
+
+
+def _emissive_mix_scene(n_lamps):
+    """An open scene (no environment light): a floor, mirrors and glass, and `n_lamps` emitters of every kind the
+    scene format has -- quads, an analytic sphere, a quad with an image texture as its emission."""
+    sb = abi.SceneBuilder()
+    g = np.random.Generator(np.random.Philox(key=17))
+    white = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.7, 0.7, 0.7)))
+    mirror = sb.add_material(abi.PTX_MAT_MIRROR, sb.add_constant_texture((0.9, 0.9, 0.9)))
+    glass = sb.add_material(abi.PTX_MAT_GLASS, sb.add_constant_texture((1, 1, 1)), sb.add_constant_texture((1, 1, 1)), 1.4)
+    lamp_const = sb.add_material(abi.PTX_MAT_EMISSIVE, sb.add_constant_texture((1.0, 0.8, 0.6), 5.0))
+    lamp_img = sb.add_material(abi.PTX_MAT_EMISSIVE, sb.add_image_texture(g.random((8, 8, 3), dtype=np.float32) * 4, abi.PTX_SAMPLER_BILINEAR))
+    q = sb.add_mesh(*scenes.quad())
+    ico = sb.add_mesh(*scenes.icosphere(2))
+    sb.add_instance(q, white, scenes.trs((0, -1, 0), scale=(3, 1, 3)))
+    sb.add_instance(ico, mirror, scenes.trs((-0.9, -0.4, 0.0), axis=(1, 2, 3), deg=20, scale=(0.6, 0.5, 0.6)))
+    sb.add_instance(ico, glass, scenes.trs((0.9, -0.4, 0.2), scale=(0.55, 0.55, 0.55)))
+    sb.add_instance(-1, white, scenes.trs((0.0, -0.6, -0.9), scale=(0.4, 0.4, 0.4)), sphere_radius=1.0)
+    for k in range(n_lamps):
+        a = 2 * np.pi * k / max(n_lamps, 1)
+        pos = (1.6 * np.cos(a), 0.9 + 0.1 * (k % 3), 1.6 * np.sin(a))
+        if k % 3 == 0:
+            sb.add_instance(q, lamp_const, scenes.trs(pos, axis=(1, 0, 0), deg=180, scale=(0.4, 1, 0.4)))
+        elif k % 3 == 1:
+            sb.add_instance(-1, lamp_const, scenes.trs(pos, scale=(0.2, 0.2, 0.2)), sphere_radius=1.0)
+        else:
+            sb.add_instance(q, lamp_img, scenes.trs(pos, axis=(1, 0, 1), deg=170, scale=(0.5, 1, 0.3)))
+    return sb
+
+
+@pytest.mark.parametrize("what", ["room_small", "room_large", "lamps3", "lamps8", "lamps9_skip_off", "no_lamp", "env"])
+@pytest.mark.parametrize("depth", [1, 5])
+def test_rays_left_out_do_not_change_the_accumulator(what, depth):
+    """By default the render leaves out rays whose answer cannot reach the image: the scattered ray of a path's last
+    vertex (pathtracer.cpp:118,163: `.second` of a depth-0 trace() is {}) and direct-lighting rays that touch no
+    primitive of an Emissive instance (pathtracer.cpp:64-76: only the emission of the first hit is used).
+    PTX_RENDER_TRACE_UNUSED_RAYS traces them all, as the reference does; the accumulators must be equal bit for bit,
+    on the one-ray-per-lane kernels and on the replenishing ones, with every kind of emitter, with more emitters
+    than the shortcut takes (it is then off), without any, and with an environment light (off as well)."""
+    w, spp = (512, 2) if what == "room_large" else (96, 6)
+    if what.startswith("room"):
+        sb = lit_scene("delta")
+    elif what == "env":
+        sb = lit_scene("env")
+    elif what == "no_lamp":
+        sb = _emissive_mix_scene(0)
+        sb.add_delta_light(abi.PTX_LIGHT_POINT, (1, 1, 1), 3.0, scenes.trs((0.0, 1.5, 0.5)))
+    else:
+        sb = _emissive_mix_scene(int(what[5]))
+    cam = camera(w, w, spp, depth, pos=(0, 0.3, 3.6))
+    tiles = capi.make_tiles(w, w, spp, 13)
+    gsc = capi.Scene(sb.desc(), keep=sb)
+    acc_d, smp_d = gsc.render_tiles(cam, tiles, SEED)
+    acc_a, smp_a = gsc.render_tiles(cam, tiles, SEED, flags=abi.PTX_RENDER_TRACE_UNUSED_RAYS)
+    gsc.close()
+    assert (smp_d == spp).all() and (smp_a == spp).all()
+    assert acc_d.any()
+    assert (acc_d == acc_a).all(), f"{int((acc_d != acc_a).sum())} accumulator words differ"
+
+
+def test_emissive_scene_same_stream(oracle):
+    """The emitter mix against the CPU checker driven by the same random stream (the checker traces every ray)."""
+    sb = _emissive_mix_scene(6)
+    w, h, spp = 96, 64, 6
+    cam = camera(w, h, spp, 4, pos=(0, 0.3, 3.6))
+    io, ig = images(oracle, sb, cam, capi.make_tiles(w, h, spp, 5))
+    assert io.mean() > 0.01
+    assert_same_stream(io, ig)

@@ -405,7 +405,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 					ps.depth -= 1;
 				}
 				ps.draws = rng.draws;
-				alive = true;
+				// A path stays in flight for what the next round can still add to it: its scattered ray's vertex
+				// (not when that ray has depth 0: nothing of its hit is used), a traced direct ray's emission, or
+				// this vertex's delta lights (added to the path's state after their occlusion pass).
+				alive = ps.depth != 0 || wants_direct || lights_written;
 			}
 		}
 		if (DELTA && !lights_written)   // no light takes part at this vertex: the occlusion pass skips the path's entries

@@ -38,8 +38,7 @@
 namespace ptx {
 
 constexpr float RAY_MINIMUM_BOUND = 0.001f;   // pathtracer.cpp:17
-constexpr uint32_t FLAG_CAMERA = 1u, FLAG_HAS_DIRECT = 2u;
-// Paths in flight per pass (216 B of state each: 14 GB at the limit).  Measured on a 268 M-path render:
+// Paths in flight per pass (188 B of state each: 12.6 GB at the limit).  Measured on a 268 M-path render:
 // 8 M paths per pass 0.67 s, 32 M 0.60 s, 128 M 0.59 s.
 constexpr uint64_t MAX_SLOTS_PER_CHUNK = 64u << 20;
 
@@ -47,15 +46,15 @@ struct alignas(16) SlotInfo {
 	uint32_t pixel, s_begin, s_count, pad;
 };
 
-struct alignas(16) PathState {            // 64 bytes per path
-	float T[3];               // throughput of the main ray's path so far
-	uint32_t depth;           // Ray::depth of the main ray
-	float L[3];               // radiance gathered so far
-	uint32_t draws;           // random numbers consumed so far
-	float Wd[3];              // weight of the pending direct ray's emission (T * attenuation [/ pdf])
-	uint32_t flags;
-	uint32_t sample, pixel, pad[2];   // which sample of which film pixel (the random stream's name)
-};
+// What a path carries from one round to the next is one 16-byte word: the throughput of its main ray's path so
+// far and, packed into the fourth component, Ray::depth of the main ray, the number of random draws consumed, and
+// two flags.  Which sample of which film pixel the path is (the random stream's name) follows from its index.
+constexpr uint32_t PATH_DEPTH_BITS = 13, PATH_DRAWS_BITS = 17;
+constexpr uint32_t PATH_MAX_DEPTH = (1u << PATH_DEPTH_BITS) - 1;   // at most 2 + 6 draws per vertex: 49 148 < 2^17
+constexpr uint32_t PATH_CAMERA = 1u << 30, PATH_HAS_DIRECT = 1u << 31;
+__device__ __forceinline__ uint32_t path_pack(uint32_t depth, uint32_t draws, uint32_t flags) { return depth | (draws << PATH_DEPTH_BITS) | flags; }
+__device__ __forceinline__ uint32_t path_depth(uint32_t w) { return w & PATH_MAX_DEPTH; }
+__device__ __forceinline__ uint32_t path_draws(uint32_t w) { return (w >> PATH_DEPTH_BITS) & ((1u << PATH_DRAWS_BITS) - 1); }
 
 struct TileRec {
 	uint32_t x_begin, y_begin, w, h, s_begin, s_count, slot_base, pad;
@@ -64,13 +63,18 @@ struct TileRec {
 // A slot is one pixel of one tile; a path is one sample of a slot.  `group` samples of every slot are in
 // flight together: path g * n_slots + slot carries the g-th sample of the current pass of `slot`
 // (neighbouring paths are neighbouring pixels).  Small films thus still fill the chip.
+// Per-path records are kept as separate arrays of 16-byte (8-byte) pieces: the lanes of a wave work on
+// neighbouring paths, so each of their loads and stores covers one contiguous kilobyte.
 struct RenderBuffers {
 	SlotInfo* slots;
 	float4* sums;         // per slot: float sum of its samples so far (rgb)
-	float4* rad;          // per path: the radiance its sample ended with
-	PathState* paths;
-	PtxRay* rays;         // 2 per path: main, direct
-	HitRec* hits;         // 2 per path
+	float4* rad;          // per path: the radiance gathered so far; what its sample ends with
+	float4* state;        // per path: throughput (xyz), packed depth / draws / flags (w)
+	float4* wd;           // per path: weight of the pending direct ray's emission (T * attenuation [/ pdf])
+	float4* ray_a[2];     // per path, [0] main ray, [1] direct ray: origin, direction.x
+	float4* ray_b[2];     //                                         direction.yz, distance bounds
+	float4* hit_a[2];     // per path and ray: distance, t, u, v
+	uint2* hit_b[2];      //                   primitive (0xFFFFFFFF: none), instance
 	uint32_t* active[2];
 	uint32_t* direct;     // the paths of the next active list whose direct ray is to be traced
 	uint32_t* counts;     // [0], [1]: sizes of active[0], active[1]; [2]: size of direct
@@ -83,6 +87,7 @@ struct RenderBuffers {
 	uint8_t* shadow_occ;
 	uint32_t n_lights;
 };
+constexpr size_t PATH_STATE_BYTES = 3 * sizeof(float4) + 2 * (2 * sizeof(float4) + sizeof(float4) + sizeof(uint2)) + 3 * sizeof(uint32_t);
 
 // Records move between registers and memory as whole 16-byte pieces (one vector load or store per
 // piece, adjacent lanes adjacent in memory) instead of one dword at a time.
@@ -165,15 +170,10 @@ __global__ void __launch_bounds__(RAYGEN_BLOCK) k_raygen(RenderBuffers rb, uint3
 			rng.start(key0, key1, si.pixel, si.s_begin + k, 0);
 			const float ox = rng.next_unit(), oy = rng.next_unit();   // Samplers::Rect::sample, samplers.cpp:13 (x first)
 			const Ray3 r = camera_ray(cam, si.pixel % cam.film_w, si.pixel / cam.film_w, ox, oy);
-			PathState ps{};
-			ps.T[0] = ps.T[1] = ps.T[2] = 1.0f;
-			ps.depth = cam.max_depth;
-			ps.draws = rng.draws;
-			ps.flags = FLAG_CAMERA;
-			ps.sample = si.s_begin + k;
-			ps.pixel = si.pixel;
-			store_rec(rb.paths + path, ps);
-			store_rec(rb.rays + 2 * path, PtxRay{{r.ox, r.oy, r.oz}, {r.dx, r.dy, r.dz}, r.tmin, r.tmax});
+			rb.state[path] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(path_pack(cam.max_depth, rng.draws, PATH_CAMERA)));
+			rb.rad[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			rb.ray_a[0][path] = make_float4(r.ox, r.oy, r.oz, r.dx);
+			rb.ray_b[0][path] = make_float4(r.dy, r.dz, r.tmin, r.tmax);
 		}
 	}
 	block_append<RAYGEN_BLOCK / 64>(live, path, out_list, out_count);
@@ -188,9 +188,10 @@ struct RenderIO {
 	uint32_t main_rays;       // 0: the main rays are not traced this round (nothing would use their hits)
 	__device__ __forceinline__ uint32_t n_main() const { return main_rays ? *n_paths : 0u; }
 	__device__ __forceinline__ uint64_t count() const { return uint64_t(n_main()) + rb.counts[2]; }
+	// a ray's name in the traversal kernels: 2 * path + (0: main ray, 1: direct ray)
 	__device__ __forceinline__ void load(uint32_t out, Ray3& r) const {
-		const float4* rp = reinterpret_cast<const float4*>(rb.rays + out);
-		const float4 a = rp[0], b = rp[1];
+		const uint32_t path = out >> 1;
+		const float4 a = (out & 1u ? rb.ray_a[1] : rb.ray_a[0])[path], b = (out & 1u ? rb.ray_b[1] : rb.ray_b[0])[path];
 		r = Ray3{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 	}
 	__device__ __forceinline__ bool fetch(uint64_t item, Ray3& r, uint32_t& out) const {
@@ -200,10 +201,9 @@ struct RenderIO {
 		return true;
 	}
 	__device__ __forceinline__ void store(uint32_t out, const SceneHit& h) const {
-		HitRec o{};
-		o.distance = h.distance, o.t = h.t, o.u = h.u, o.v = h.v;
-		o.prim = h.hit ? h.prim : 0xFFFFFFFFu, o.inst = h.inst;
-		store_rec(rb.hits + out, o);
+		const uint32_t path = out >> 1;
+		(out & 1u ? rb.hit_a[1] : rb.hit_a[0])[path] = make_float4(h.distance, h.t, h.u, h.v);
+		(out & 1u ? rb.hit_b[1] : rb.hit_b[0])[path] = make_uint2(h.hit ? h.prim : 0xFFFFFFFFu, h.inst);
 	}
 };
 
@@ -290,138 +290,159 @@ __device__ __forceinline__ Surface rebuild_surface(const SceneRec& sc, const Sha
 // (any-hit queries, the replenishing two-level kernel on large batches) and k_apply_shadows adds the unoccluded ones
 // to the path's radiance in light order -- the same additions in the same order as the reference's loop, since
 // nothing else touches the radiance between them and the next level's first addition.
+// k0: the first sample (per slot) of the pass in flight.
 template<bool DELTA>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables sh, RenderBuffers rb, const uint32_t* __restrict__ list,
-                                               const uint32_t* __restrict__ count, uint32_t key0, uint32_t key1,
+                                               const uint32_t* __restrict__ count, uint32_t k0, uint32_t key0, uint32_t key1,
                                                uint32_t* __restrict__ next_list, uint32_t* __restrict__ next_count) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	bool alive = false, wants_direct = false;
-	uint32_t slot = 0;
+	uint32_t path = 0;
 	if (i < *count) {
-		slot = list[i];
-		PathState ps = load_rec(rb.paths + slot);
-		V3f T = v3(ps.T[0], ps.T[1], ps.T[2]), L = v3(ps.L[0], ps.L[1], ps.L[2]);
+		path = list[i];
+		const float4 st = rb.state[path];
+		V3f T = v3(st.x, st.y, st.z);
+		const uint32_t word = __float_as_uint(st.w);
+		uint32_t depth = path_depth(word);
+		const bool camera = word & PATH_CAMERA;
 		bool lights_written = false;
+		// The radiance gathered so far stays in memory; the few vertices that add to it (a camera ray meeting a lamp
+		// or the environment, a direct ray that found light) read it, add in the reference's order, and write it back.
+		V3f L = v3(0, 0, 0);
+		bool L_loaded = false;
+		auto add_radiance = [&](V3f x) {
+			if (!L_loaded) {
+				const float4 l = rb.rad[path];
+				L = v3(l.x, l.y, l.z), L_loaded = true;
+			}
+			L = L + x;
+		};
 
 		// ---- the direct ray traced last round: trace(rng, new_in_ray).first (pathtracer.cpp:71-76)
-		if (ps.flags & FLAG_HAS_DIRECT) {
+		if (word & PATH_HAS_DIRECT) {
 			// the direct ray itself is read back only where its direction or origin matters
-			const HitRec dh = load_rec(rb.hits + 2 * slot + 1);
+			const float4 da = rb.hit_a[1][path];
+			const uint2 db = rb.hit_b[1][path];
 			V3f first = v3(0, 0, 0);
-			if (dh.prim == 0xFFFFFFFFu) {
+			if (db.x == 0xFFFFFFFFu) {
 				if (sh.n_env_lights) {   // pathtracer.cpp:129-136
-					const PtxRay dr = load_rec(rb.rays + 2 * slot + 1);
-					first = env_radiance(sh, v3(dr.d[0], dr.d[1], dr.d[2]));
+					const float4 ra = rb.ray_a[1][path], rbb = rb.ray_b[1][path];
+					first = env_radiance(sh, v3(ra.w, rbb.x, rbb.y));
 				}
 			} else {
 				// depth 0: {emissive, {}} (pathtracer.cpp:160-163).  Only an emissive surface with an image texture
 				// needs the hit rebuilt (for its uv); everything else is decided by the instance's material.
-				const int32_t mat_id = sc.insts[dh.inst].material;
+				const int32_t mat_id = sc.insts[db.y].material;
 				if (mat_id >= 0) {
 					const MatRec dm = sh.materials[mat_id];
 					if (dm.type == PTX_MAT_EMISSIVE) {
 						if (sh.textures[dm.tex_a].type == PTX_TEX_CONSTANT) {
 							first = tex_evaluate(sh, dm.tex_a, 0.0f, 0.0f);
 						} else {
-							const PtxRay dr = load_rec(rb.rays + 2 * slot + 1);
-							const Ray3 r{dr.o[0], dr.o[1], dr.o[2], dr.d[0], dr.d[1], dr.d[2], dr.tmin, dr.tmax};
+							const float4 ra = rb.ray_a[1][path], rbb = rb.ray_b[1][path];
+							const Ray3 r{ra.x, ra.y, ra.z, ra.w, rbb.x, rbb.y, rbb.z, rbb.w};
+							HitRec dh{};
+							dh.distance = da.x, dh.t = da.y, dh.u = da.z, dh.v = da.w, dh.prim = db.x, dh.inst = db.y;
 							const Surface s = rebuild_surface(sc, sh, r, dh);
 							first = bsdf_emission(sh, dm, s.u, s.v);
 						}
 					}
 				}
 			}
-			L = L + first * v3(ps.Wd[0], ps.Wd[1], ps.Wd[2]);
+			const float4 wd = rb.wd[path];
+			add_radiance(first * v3(wd.x, wd.y, wd.z));
 		}
 
 		// ---- the main ray
-		const PtxRay mr = load_rec(rb.rays + 2 * slot);
-		const HitRec mh = load_rec(rb.hits + 2 * slot);
-		const V3f ray_o = v3(mr.o[0], mr.o[1], mr.o[2]), ray_d = v3(mr.d[0], mr.d[1], mr.d[2]);
-		const bool camera = ps.flags & FLAG_CAMERA;
-		ps.flags = 0;
-		if (!camera && ps.depth == 0) {
+		if (!camera && depth == 0) {
 			// the scattered ray of the path's last vertex: trace() would return {emissive, {}} for it and
 			// sample_indirect_lighting uses `.second` only (pathtracer.cpp:118,163); it may not even have been traced
-		} else if (mh.prim == 0xFFFFFFFFu || sc.insts[mh.inst].material < 0) {
-			// miss: {env, {}} -- only a camera ray's (or a direct ray's) `.first` is ever used
-			if (camera && mh.prim == 0xFFFFFFFFu) L = L + env_radiance(sh, ray_d);
 		} else {
-			const Ray3 r{mr.o[0], mr.o[1], mr.o[2], mr.d[0], mr.d[1], mr.d[2], mr.tmin, mr.tmax};
-			Surface s = rebuild_surface(sc, sh, r, mh);
-			const MatRec m = sh.materials[s.material];
-			if (!mat_is_sided(m.type) && dot3(s.normal, ray_d) > 0.0f) s.normal = -s.normal;   // pathtracer.cpp:143-145
-			const Frame f = frame_from_normal(s.normal);
-			const V3f out_dir = unit(f.to_local(ray_o - s.position));   // pathtracer.cpp:153
-			const V3f emissive = bsdf_emission(sh, m, s.u, s.v);
-			if (camera) L = L + emissive;   // an indirect ray contributes `.second` only
-			if (ps.depth != 0 && m.type != PTX_MAT_EMISSIVE) {   // pathtracer.cpp:163
-				// sum_delta_lights (pathtracer.cpp:645-666): shadow rays and contributions for the occlusion pass
-				if (DELTA && !mat_is_specular(m.type)) {
-					lights_written = true;
-					for (uint32_t li = 0; li < sh.n_delta_lights; li++) {
-						const size_t item = size_t(slot) * sh.n_delta_lights + li;
-						const IncomingRec inc = light_incoming(sh.delta_lights[li], s.position);
-						const V3f in_dir = f.to_local(inc.direction);
-						const V3f att = bsdf_evaluate(sh, m, in_dir, s.u, s.v);   // evaluate(out_dir, in_dir): cosine of in_dir
-						if (0.2126f * att.x + 0.7152f * att.y + 0.0722f * att.z == 0.0f) {
-							rb.shadow_add[item] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-							continue;
+			const float4 ma = rb.ray_a[0][path], mb = rb.ray_b[0][path];
+			const float4 ha = rb.hit_a[0][path];
+			const uint2 hb = rb.hit_b[0][path];
+			const V3f ray_o = v3(ma.x, ma.y, ma.z), ray_d = v3(ma.w, mb.x, mb.y);
+			if (hb.x == 0xFFFFFFFFu || sc.insts[hb.y].material < 0) {
+				// miss: {env, {}} -- only a camera ray's (or a direct ray's) `.first` is ever used
+				if (camera && hb.x == 0xFFFFFFFFu && sh.n_env_lights) add_radiance(env_radiance(sh, ray_d));
+			} else {
+				const Ray3 r{ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+				HitRec mh{};
+				mh.distance = ha.x, mh.t = ha.y, mh.u = ha.z, mh.v = ha.w, mh.prim = hb.x, mh.inst = hb.y;
+				Surface s = rebuild_surface(sc, sh, r, mh);
+				const MatRec m = sh.materials[s.material];
+				if (!mat_is_sided(m.type) && dot3(s.normal, ray_d) > 0.0f) s.normal = -s.normal;   // pathtracer.cpp:143-145
+				const Frame f = frame_from_normal(s.normal);
+				const V3f out_dir = unit(f.to_local(ray_o - s.position));   // pathtracer.cpp:153
+				// an indirect ray contributes `.second` only; every material but Emissive emits a zero Spectrum
+				if (camera && m.type == PTX_MAT_EMISSIVE) add_radiance(bsdf_emission(sh, m, s.u, s.v));
+				if (depth != 0 && m.type != PTX_MAT_EMISSIVE) {   // pathtracer.cpp:163
+					// sum_delta_lights (pathtracer.cpp:645-666): shadow rays and contributions for the occlusion pass
+					if (DELTA && !mat_is_specular(m.type)) {
+						lights_written = true;
+						for (uint32_t li = 0; li < sh.n_delta_lights; li++) {
+							const size_t item = size_t(path) * sh.n_delta_lights + li;
+							const IncomingRec inc = light_incoming(sh.delta_lights[li], s.position);
+							const V3f in_dir = f.to_local(inc.direction);
+							const V3f att = bsdf_evaluate(sh, m, in_dir, s.u, s.v);   // evaluate(out_dir, in_dir): cosine of in_dir
+							if (0.2126f * att.x + 0.7152f * att.y + 0.0722f * att.z == 0.0f) {
+								rb.shadow_add[item] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+								continue;
+							}
+							const V3f sd = unit(inc.direction);   // Ray's constructor
+							store_rec(rb.shadow_rays + item, PtxRay{{s.position.x, s.position.y, s.position.z}, {sd.x, sd.y, sd.z}, SH_EPS, inc.distance - SH_EPS});
+							const V3f add = T * (att * inc.radiance);
+							rb.shadow_add[item] = make_float4(add.x, add.y, add.z, 1.0f);
 						}
-						const V3f sd = unit(inc.direction);   // Ray's constructor
-						store_rec(rb.shadow_rays + item, PtxRay{{s.position.x, s.position.y, s.position.z}, {sd.x, sd.y, sd.z}, SH_EPS, inc.distance - SH_EPS});
-						const V3f add = T * (att * inc.radiance);
-						rb.shadow_add[item] = make_float4(add.x, add.y, add.z, 1.0f);
 					}
-				}
-				PathRng rng;
-				rng.start(key0, key1, ps.pixel, ps.sample, ps.draws);
-				// sample_direct_lighting_task4 (pathtracer.cpp:34-78): weight = attenuation [/ pdf]
-				{
-					const ScatterRec sc1 = bsdf_scatter(sh, m, rng, out_dir, s.u, s.v);
-					const V3f in_world = unit(f.to_world(sc1.direction));   // Ray's constructor normalises
-					V3f w = sc1.specular ? sc1.attenuation : bsdf_evaluate(sh, m, out_dir, s.u, s.v);   // evaluate(in_dir, out_dir): `in` = out_dir
-					if (!sc1.specular) w = w / bsdf_pdf(m, out_dir);                                      // pdf(in_dir, out_dir): `in` = out_dir
-					const V3f Wd = T * w;
-					// The ray brings back `first`, the emission of the first surface it meets; the path gains first * Wd.
-					// Where first is provably zero and Wd finite that is +-0, and L + (+-0) == L: the ray is left out.
-					wants_direct = true;
-					if (sh.direct_skip && finite3(Wd))
-						wants_direct = direct_ray_may_see_light(sc, sh, Ray3{s.position.x, s.position.y, s.position.z, in_world.x, in_world.y, in_world.z, RAY_MINIMUM_BOUND, INFINITY});
-					if (wants_direct) {
-						ps.Wd[0] = Wd.x, ps.Wd[1] = Wd.y, ps.Wd[2] = Wd.z;
-						store_rec(rb.rays + 2 * slot + 1, PtxRay{{s.position.x, s.position.y, s.position.z}, {in_world.x, in_world.y, in_world.z}, RAY_MINIMUM_BOUND, INFINITY});
-						ps.flags |= FLAG_HAS_DIRECT;
+					const SlotInfo si = load_rec(rb.slots + path % rb.n_slots);
+					PathRng rng;
+					rng.start(key0, key1, si.pixel, si.s_begin + k0 + path / rb.n_slots, path_draws(word));
+					// sample_direct_lighting_task4 (pathtracer.cpp:34-78): weight = attenuation [/ pdf]
+					{
+						const ScatterRec sc1 = bsdf_scatter(sh, m, rng, out_dir, s.u, s.v);
+						const V3f in_world = unit(f.to_world(sc1.direction));   // Ray's constructor normalises
+						V3f w = sc1.specular ? sc1.attenuation : bsdf_evaluate(sh, m, out_dir, s.u, s.v);   // evaluate(in_dir, out_dir): `in` = out_dir
+						if (!sc1.specular) w = w / bsdf_pdf(m, out_dir);                                      // pdf(in_dir, out_dir): `in` = out_dir
+						const V3f Wd = T * w;
+						// The ray brings back `first`, the emission of the first surface it meets; the path gains first * Wd.
+						// Where first is provably zero and Wd finite that is +-0, and L + (+-0) == L: the ray is left out.
+						wants_direct = true;
+						if (sh.direct_skip && finite3(Wd))
+							wants_direct = direct_ray_may_see_light(sc, sh, Ray3{s.position.x, s.position.y, s.position.z, in_world.x, in_world.y, in_world.z, RAY_MINIMUM_BOUND, INFINITY});
+						if (wants_direct) {
+							rb.wd[path] = make_float4(Wd.x, Wd.y, Wd.z, 0.0f);
+							rb.ray_a[1][path] = make_float4(s.position.x, s.position.y, s.position.z, in_world.x);
+							rb.ray_b[1][path] = make_float4(in_world.y, in_world.z, RAY_MINIMUM_BOUND, INFINITY);
+						}
 					}
+					// sample_indirect_lighting (pathtracer.cpp:81-124)
+					{
+						const ScatterRec sc2 = bsdf_scatter(sh, m, rng, out_dir, s.u, s.v);
+						const V3f in_world = unit(f.to_world(sc2.direction));
+						V3f w = sc2.specular ? sc2.attenuation : bsdf_evaluate(sh, m, out_dir, s.u, s.v);
+						if (!sc2.specular) w = w / bsdf_pdf(m, out_dir);
+						T = T * w;
+						depth -= 1;
+						if (depth != 0) {   // a ray of depth 0 is not traced (see above)
+							rb.ray_a[0][path] = make_float4(s.position.x, s.position.y, s.position.z, in_world.x);
+							rb.ray_b[0][path] = make_float4(in_world.y, in_world.z, RAY_MINIMUM_BOUND, INFINITY);
+						}
+					}
+					// A path stays in flight for what the next round can still add to it: its scattered ray's vertex
+					// (not when that ray has depth 0: nothing of its hit is used), a traced direct ray's emission, or
+					// this vertex's delta lights (added to the path's radiance after their occlusion pass).
+					alive = depth != 0 || wants_direct || lights_written;
+					if (alive) rb.state[path] = make_float4(T.x, T.y, T.z, __uint_as_float(path_pack(depth, rng.draws, wants_direct ? PATH_HAS_DIRECT : 0u)));
 				}
-				// sample_indirect_lighting (pathtracer.cpp:81-124)
-				{
-					const ScatterRec sc2 = bsdf_scatter(sh, m, rng, out_dir, s.u, s.v);
-					const V3f in_world = unit(f.to_world(sc2.direction));
-					V3f w = sc2.specular ? sc2.attenuation : bsdf_evaluate(sh, m, out_dir, s.u, s.v);
-					if (!sc2.specular) w = w / bsdf_pdf(m, out_dir);
-					T = T * w;
-					store_rec(rb.rays + 2 * slot, PtxRay{{s.position.x, s.position.y, s.position.z}, {in_world.x, in_world.y, in_world.z}, RAY_MINIMUM_BOUND, INFINITY});
-					ps.depth -= 1;
-				}
-				ps.draws = rng.draws;
-				// A path stays in flight for what the next round can still add to it: its scattered ray's vertex
-				// (not when that ray has depth 0: nothing of its hit is used), a traced direct ray's emission, or
-				// this vertex's delta lights (added to the path's state after their occlusion pass).
-				alive = ps.depth != 0 || wants_direct || lights_written;
 			}
 		}
 		if (DELTA && !lights_written)   // no light takes part at this vertex: the occlusion pass skips the path's entries
-			for (uint32_t li = 0; li < sh.n_delta_lights; li++) rb.shadow_add[size_t(slot) * sh.n_delta_lights + li] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		if (alive) {
-			ps.T[0] = T.x, ps.T[1] = T.y, ps.T[2] = T.z, ps.L[0] = L.x, ps.L[1] = L.y, ps.L[2] = L.z;
-			store_rec(rb.paths + slot, ps);
-		} else {
-			rb.rad[slot] = make_float4(L.x, L.y, L.z, 0.0f);   // folded into the slot's sum in sample order by k_sum_pass
-		}
+			for (uint32_t li = 0; li < sh.n_delta_lights; li++) rb.shadow_add[size_t(path) * sh.n_delta_lights + li] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (L_loaded) rb.rad[path] = make_float4(L.x, L.y, L.z, 0.0f);   // folded into the slot's sum in sample order by k_sum_pass
 	}
-	block_append<SHADE_BLOCK / 64>(alive, slot, next_list, next_count);
-	block_append<SHADE_BLOCK / 64>(wants_direct, slot, rb.direct, rb.counts + 2);
+	block_append<SHADE_BLOCK / 64>(alive, path, next_list, next_count);
+	block_append<SHADE_BLOCK / 64>(wants_direct, path, rb.direct, rb.counts + 2);
 }
 
 // The shadow rays k_shade left, as a ray source / answer sink of the occlusion kernels: item k is light k % n_lights
@@ -460,25 +481,20 @@ __global__ void __launch_bounds__(256) k_shadow_plain(SceneRec sc, ShadowIO io) 
 }
 
 // `if (!shadow.hit) radiance += attenuation * incoming.radiance` (pathtracer.cpp:660-662) for every light in order.
-// A path that had lights taking part is still alive (it scattered at the same vertex), so its radiance is in its state.
 __global__ void __launch_bounds__(256) k_apply_shadows(RenderBuffers rb, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= *count) return;
-	const uint32_t slot = list[i];
-	float Lx = 0.0f, Ly = 0.0f, Lz = 0.0f;
+	const uint32_t path = list[i];
+	float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	bool any = false;
 	for (uint32_t li = 0; li < rb.n_lights; li++) {
-		const size_t item = size_t(slot) * rb.n_lights + li;
+		const size_t item = size_t(path) * rb.n_lights + li;
 		const float4 add = rb.shadow_add[item];
 		if (add.w == 0.0f || rb.shadow_occ[item]) continue;
-		if (!any) {
-			const PathState& ps = rb.paths[slot];
-			Lx = ps.L[0], Ly = ps.L[1], Lz = ps.L[2];
-			any = true;
-		}
-		Lx += add.x, Ly += add.y, Lz += add.z;
+		if (!any) L = rb.rad[path], any = true;
+		L.x += add.x, L.y += add.y, L.z += add.z;
 	}
-	if (any) rb.paths[slot].L[0] = Lx, rb.paths[slot].L[1] = Ly, rb.paths[slot].L[2] = Lz;
+	if (any) rb.rad[path] = L;
 }
 
 // The samples of one pass added to their slot's sum in sample order, so that the float sum per pixel is
@@ -546,6 +562,7 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 	if (!s || !cam || (n_tiles && !tiles) || !accum_rgb || !samples) return fail(PTX_ERR_INVALID, "ptx_render_tiles: null argument");
 	if (s->rec.mesh_only) return fail(PTX_ERR_INVALID, "ptx_render_tiles: the scene was created with ptx_scene_create_mesh and has no materials");
 	if (!cam->film_width || !cam->film_height) return fail(PTX_ERR_INVALID, "ptx_render_tiles: empty film");
+	if (cam->film_max_ray_depth > PATH_MAX_DEPTH) return fail(PTX_ERR_UNSUPPORTED, "ptx_render_tiles: film_max_ray_depth above 8191");
 	for (uint32_t i = 0; i < n_tiles; i++) {
 		const PtxTile& t = tiles[i];
 		if (t.x_begin > t.x_end || t.y_begin > t.y_end || t.s_begin > t.s_end || t.x_end > cam->film_width || t.y_end > cam->film_height)
@@ -610,19 +627,30 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		// one allocation for all per-slot and per-path state
 		const uint32_t n_lights = s->shade.n_delta_lights;
 		const size_t shadow_bytes = size_t(n_lights) * (sizeof(PtxRay) + sizeof(float4) + 1) + 16;   // per path
-		const size_t bytes = n_slots * (sizeof(SlotInfo) + sizeof(float4)) + n_paths * (sizeof(float4) + sizeof(PathState) + 2 * sizeof(PtxRay) + 2 * sizeof(HitRec) + 3 * sizeof(uint32_t) + (n_lights ? shadow_bytes : 0)) + 256;
+		const size_t bytes = n_slots * (sizeof(SlotInfo) + sizeof(float4)) + n_paths * (PATH_STATE_BYTES + (n_lights ? shadow_bytes : 0)) + 256;
 		if (int rc = device_alloc(s, 3, bytes, &p)) return rc;
 		char* base = static_cast<char*>(p);
-		rb.counts = reinterpret_cast<uint32_t*>(base), base += 256;
-		rb.hits = reinterpret_cast<HitRec*>(base), base += n_paths * 2 * sizeof(HitRec);
-		rb.rays = reinterpret_cast<PtxRay*>(base), base += n_paths * 2 * sizeof(PtxRay);
-		rb.paths = reinterpret_cast<PathState*>(base), base += n_paths * sizeof(PathState);
-		rb.rad = reinterpret_cast<float4*>(base), base += n_paths * sizeof(float4);
-		rb.sums = reinterpret_cast<float4*>(base), base += n_slots * sizeof(float4);
-		rb.slots = reinterpret_cast<SlotInfo*>(base), base += n_slots * sizeof(SlotInfo);
-		rb.active[0] = reinterpret_cast<uint32_t*>(base), base += n_paths * sizeof(uint32_t);
-		rb.active[1] = reinterpret_cast<uint32_t*>(base), base += n_paths * sizeof(uint32_t);
-		rb.direct = reinterpret_cast<uint32_t*>(base), base += n_paths * sizeof(uint32_t);
+		auto take = [&](size_t count, size_t elem) {
+			char* at = base;
+			base += count * elem;
+			return at;
+		};
+		rb.counts = reinterpret_cast<uint32_t*>(take(1, 256));
+		rb.state = reinterpret_cast<float4*>(take(n_paths, sizeof(float4)));
+		rb.rad = reinterpret_cast<float4*>(take(n_paths, sizeof(float4)));
+		rb.wd = reinterpret_cast<float4*>(take(n_paths, sizeof(float4)));
+		for (int which = 0; which < 2; which++) {
+			rb.ray_a[which] = reinterpret_cast<float4*>(take(n_paths, sizeof(float4)));
+			rb.ray_b[which] = reinterpret_cast<float4*>(take(n_paths, sizeof(float4)));
+			rb.hit_a[which] = reinterpret_cast<float4*>(take(n_paths, sizeof(float4)));
+		}
+		rb.sums = reinterpret_cast<float4*>(take(n_slots, sizeof(float4)));
+		rb.slots = reinterpret_cast<SlotInfo*>(take(n_slots, sizeof(SlotInfo)));
+		rb.hit_b[0] = reinterpret_cast<uint2*>(take(n_paths, sizeof(uint2)));
+		rb.hit_b[1] = reinterpret_cast<uint2*>(take(n_paths, sizeof(uint2)));
+		rb.active[0] = reinterpret_cast<uint32_t*>(take(n_paths, sizeof(uint32_t)));
+		rb.active[1] = reinterpret_cast<uint32_t*>(take(n_paths, sizeof(uint32_t)));
+		rb.direct = reinterpret_cast<uint32_t*>(take(n_paths, sizeof(uint32_t)));
 		rb.n_lights = n_lights;
 		if (n_lights) {
 			base += (16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15;
@@ -665,7 +693,7 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 				PTX_HIP(hipMemsetAsync(rb.counts + 2, 0, sizeof(uint32_t), s->stream));   // the direct rays just traced are consumed; k_shade lists the next ones
 				const bool delta = n_lights != 0;
 				const auto shade = delta ? k_shade<true> : k_shade<false>;
-				hipLaunchKernelGGL(shade, dim3((np + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->rec, shade_tables, rb, rb.active[cur], rb.counts + cur, key0, key1,
+				hipLaunchKernelGGL(shade, dim3((np + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->rec, shade_tables, rb, rb.active[cur], rb.counts + cur, k, key0, key1,
 				                   rb.active[cur ^ 1], rb.counts + (cur ^ 1));
 				if (delta && round < cam->film_max_ray_depth) {   // the vertex of depth 0 gathers no light
 					// the occlusion pass over the shadow rays of the paths just shaded, then their contributions in light order

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out", "prof")
 P = os.path.join(ROOT, "profiles")
 RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
-KERNEL = "k_mesh_persistent<1, false>"
+KERNEL = "k_mesh_persistent<1, false"      # <culled, closest[, binary tree]>
 N_RAYS = 16777216.0
 CUS = 256
 

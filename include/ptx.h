@@ -48,10 +48,15 @@ enum {
 	 *   node whose ancestor chain passes BBox::hit(ray,(0,inf)), left before right, no culling
 	 *   by the running closest distance.  Identical to the reference by construction.
 	 * CULLED visits children near-to-far and skips a subtree whose slab entry is beyond the
-	 *   running closest distance by more than a guard band; ties are still resolved as the
+	 *   running closest distance by more than a guard band (1 % of that distance); ties are still resolved as the
 	 *   reference resolves them (largest position in the BVH-ordered primitive array wins,
-	 *   trace.h:28-36).  Same answers as REFERENCE on well-conditioned input; verified, not
-	 *   proven (a near-parallel ray/triangle pair can compute a distance far from the true one).
+	 *   trace.h:28-36).  Same answers as REFERENCE wherever the distances Triangle::hit computes mean
+	 *   something: its distance carries a relative error of about 2^-22 over the sine of the angle between
+	 *   ray and triangle plane, and the guard band covers angles down to 0.002 degrees.  Where a ray lies IN
+	 *   the plane of a triangle it passes (to within about 1e-6 rad) all of Triangle::hit's determinants are
+	 *   rounding noise, the reference may accept the triangle at a noise distance, and only a walk that tests
+	 *   every triangle the reference tests reproduces that: REFERENCE does, CULLED may skip the triangle.
+	 *   Measured on adversarial ray sets and on 16.7 M random rays per benchmark run (0 differences there).
 	 *   A ray with a NaN or infinite component, or whose hit distance comes out NaN, is walked in
 	 *   the reference order whatever this flag says: with NaN distances Trace::min's winner is a
 	 *   matter of test order.

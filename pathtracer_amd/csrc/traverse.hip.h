@@ -25,7 +25,14 @@
 namespace ptx {
 
 constexpr int STACK_CAP = 64;            // traversal stack entries per lane
-constexpr float CULL_SCALE = 1.0001f;    // guard band of the culled modes (see ptx.h)
+#ifndef PTX_CULL_SCALE
+#define PTX_CULL_SCALE 1.01f
+#endif
+// Guard band of the culled modes (see ptx.h): a subtree is skipped only when its box entry lies more than 1 % beyond
+// the running closest distance.  Triangle::hit's distance carries a relative error of about 2^-22 / sin(grazing
+// angle), so the band covers every hit whose ray meets its triangle at more than 0.002 degrees.  Measured cost
+// against a band of 0.01 %: 0.5 % on incoherent rays over a 1M-triangle mesh, 1-2 % on instanced-scene renders.
+constexpr float CULL_SCALE = PTX_CULL_SCALE;
 constexpr float CULL_BIAS = 1e-7f;
 constexpr uint32_t REF_NONE = 0xFFFFFFFEu;   // transient: "take the next pending subtree" (see node_decide)
 constexpr uint32_t REF_DONE = 0xFFFFFFFFu;   // leaf-shaped sentinel (no real leaf has both flag bits, start 2^26-1 and count 15)

@@ -394,6 +394,13 @@ def main():
     bvh = capi.Bvh(verts=verts, indices=idx, max_leaf_size=4)
     build_s = time.perf_counter() - t0
     nodes, order = bvh.nodes(), bvh.order()
+    # the same tree from the GPU builder (what scene creation uses for meshes of this size): time, and identity
+    capi.Bvh(verts=verts[:64], indices=idx[:8] % 64, max_leaf_size=4, gpu_device=local_rank).close()   # code load
+    t0 = time.perf_counter()
+    gbvh = capi.Bvh(verts=verts, indices=idx, max_leaf_size=4, gpu_device=local_rank)
+    gpu_build_s = time.perf_counter() - t0
+    gpu_build_identical = bool(gbvh.built_on_device and gbvh.nodes().tobytes() == nodes.tobytes() and np.array_equal(gbvh.order(), order))
+    gbvh.close()
     scene = capi.Scene.from_mesh(verts, idx[order], nodes=nodes, device=local_rank)
     scene.set_stream(torch.cuda.current_stream().cuda_stream)
     rays_h = synth.rays(args.rays, key=synth.RAY_KEY + 7919 * rank)
@@ -478,7 +485,7 @@ def main():
         "rank_devices": rank_devices,
         "config": {"workload": f"config 3: {n} incoherent rays per GPU vs {args.tris}-triangle soup BVH (max_leaf 4), closest-hit (t, primitive id)",
                    "traversal": "culled" if headline_mode == abi.PTX_TRAVERSE_CULLED else "reference", "rays_per_gpu": n,
-                   "triangles": args.tris, "bvh_nodes": int(len(nodes)), "bvh_build_s": round(build_s, 3)},
+                   "triangles": args.tris, "bvh_nodes": int(len(nodes)), "bvh_build_s": round(build_s, 3), "bvh_build_gpu_s": round(gpu_build_s, 4), "bvh_gpu_build_identical_to_host": gpu_build_identical},
         "parity": {"culled_vs_reference_mode_mismatches": mismatch_closest, "anyhit_culled_vs_reference_mismatches": mismatch_any,
                    "rays_checked": n, "hit_fraction": round(hit_fraction, 4)},
         "step_device_ms": round(step_ms, 4), "dominant_kernel": "k_mesh_persistent<culled, closest>", "dominant_kernel_ms": round(kernel_ms, 4),

@@ -128,6 +128,14 @@ int ptx_bvh_build(const float* boxes, uint32_t n, uint32_t max_leaf_size, ptx_bv
  * vertices are 8 floats each (position, normal, uv: Tri_Mesh_Vert, tri_mesh.h:13-17). */
 int ptx_bvh_build_triangles(const float* verts, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris,
                             uint32_t max_leaf_size, ptx_bvh_t* out);
+/* The same builder on the GPU `device` (BVH::build / buildRecursive, bvh.cpp:31-243, all nodes of a tree level refined
+ * together): node array, primitive order and statistics equal ptx_bvh_build's byte for byte.  Inputs that hold a
+ * negative zero or a NaN among the box bounds (where the reference's std::min / std::max depend on the order of
+ * their arguments) and empty inputs are built on the host; ptx_bvh_built_on_device tells which happened. */
+int ptx_bvh_build_gpu(int device, const float* boxes, uint32_t n, uint32_t max_leaf_size, ptx_bvh_t* out);
+int ptx_bvh_build_triangles_gpu(int device, const float* verts, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris,
+                                uint32_t max_leaf_size, ptx_bvh_t* out);
+int ptx_bvh_built_on_device(ptx_bvh_t bvh);                 /* 1 / 0 */
 uint32_t ptx_bvh_num_nodes(ptx_bvh_t bvh);
 uint32_t ptx_bvh_num_prims(ptx_bvh_t bvh);
 uint32_t ptx_bvh_max_depth(ptx_bvh_t bvh);

@@ -42,6 +42,9 @@ def lib():
     L.ptx_device_count.restype = C.c_int
     L.ptx_bvh_build.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.ptx_bvh_build_triangles.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.ptx_bvh_build_gpu.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.ptx_bvh_build_triangles_gpu.argtypes = [C.c_int, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.ptx_bvh_built_on_device.argtypes = [vp]
     for f in ("ptx_bvh_num_nodes", "ptx_bvh_num_prims", "ptx_bvh_max_depth"):
         getattr(L, f).restype = C.c_uint32
         getattr(L, f).argtypes = [vp]
@@ -119,17 +122,28 @@ def _addr(x):
 
 
 class Bvh:
-    """Host tree: PT::BVH<P>::build (bvh.cpp:31-243) over boxes or over an indexed triangle mesh."""
+    """PT::BVH<P>::build (bvh.cpp:31-243) over boxes or over an indexed triangle mesh, by the host builder or
+    (gpu_device given) by the GPU builder; both give the same tree."""
 
-    def __init__(self, boxes=None, verts=None, indices=None, max_leaf_size=4):
+    def __init__(self, boxes=None, verts=None, indices=None, max_leaf_size=4, gpu_device=None):
         self.h = vp()
         if boxes is not None:
             boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
-            check(lib().ptx_bvh_build(boxes.ctypes.data, len(boxes), max_leaf_size, C.byref(self.h)))
+            if gpu_device is None:
+                check(lib().ptx_bvh_build(boxes.ctypes.data, len(boxes), max_leaf_size, C.byref(self.h)))
+            else:
+                check(lib().ptx_bvh_build_gpu(gpu_device, boxes.ctypes.data, len(boxes), max_leaf_size, C.byref(self.h)))
         else:
             verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 8)
             indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
-            check(lib().ptx_bvh_build_triangles(verts.ctypes.data, len(verts), indices.ctypes.data, len(indices), max_leaf_size, C.byref(self.h)))
+            if gpu_device is None:
+                check(lib().ptx_bvh_build_triangles(verts.ctypes.data, len(verts), indices.ctypes.data, len(indices), max_leaf_size, C.byref(self.h)))
+            else:
+                check(lib().ptx_bvh_build_triangles_gpu(gpu_device, verts.ctypes.data, len(verts), indices.ctypes.data, len(indices), max_leaf_size, C.byref(self.h)))
+
+    @property
+    def built_on_device(self):
+        return bool(lib().ptx_bvh_built_on_device(self.h))
 
     def close(self):
         if self.h:

@@ -38,6 +38,10 @@ void triangle_boxes(const float* verts, const uint32_t* indices, uint32_t n_tris
 // PT::BVH<P>::build + buildRecursive (bvh.cpp:31-243) over n boxes (6 floats each).
 void build_bvh(const float* boxes, uint32_t n, uint32_t max_leaf_size, HostBvh& out);
 
+// The same tree built on the GPU `device` (bvh_build_gpu.hip).  `used_gpu` is false when the input went to the
+// host builder instead (empty, or a negative zero / NaN among the box bounds).  Returns a PtxStatus.
+int build_bvh_gpu(int device, const float* boxes, uint32_t n, uint32_t max_leaf_size, HostBvh& out, bool& used_gpu);
+
 // Depth of a tree given as a node array (for injected trees).  Returns false when the
 // array is not a tree rooted at 0 (child index out of range, cycle, range out of bounds).
 bool validate_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_prims, uint32_t& max_depth);

@@ -357,7 +357,16 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 		bvh.order.resize(m.n_tris);
 		for (uint32_t i = 0; i < m.n_tris; i++) bvh.order[i] = i;
 	} else if (m.use_bvh) {
-		build_bvh(boxes.data(), m.n_tris, m.max_leaf_size ? m.max_leaf_size : 4, bvh);
+		// Large meshes are built on the GPU the scene lives on (the same tree, byte for byte; a few times faster);
+		// PTX_GPU_BUILD=0 keeps the host builder, =1 sends every mesh to the GPU.
+		static const int gpu_build = getenv("PTX_GPU_BUILD") ? atoi(getenv("PTX_GPU_BUILD")) : -1;
+		const uint32_t leaf = m.max_leaf_size ? m.max_leaf_size : 4;
+		if (gpu_build == 1 || (gpu_build != 0 && m.n_tris >= (1u << 17))) {
+			bool on_device = false;
+			if (int rc = build_bvh_gpu(s->device, boxes.data(), m.n_tris, leaf, bvh, on_device)) return rc;
+		} else {
+			build_bvh(boxes.data(), m.n_tris, leaf, bvh);
+		}
 	} else {
 		bvh.order.resize(m.n_tris);
 		for (uint32_t i = 0; i < m.n_tris; i++) bvh.order[i] = i;
@@ -694,6 +703,29 @@ int ptx_bvh_build_triangles(const float* verts, uint32_t n_verts, const uint32_t
 	triangle_boxes(verts, indices, n_tris, boxes);
 	return ptx_bvh_build(boxes.data(), n_tris, max_leaf_size, out);
 }
+
+int ptx_bvh_build_gpu(int device, const float* boxes, uint32_t n, uint32_t max_leaf_size, ptx_bvh_t* out) {
+	if (!out || (n && !boxes) || max_leaf_size == 0) return fail(PTX_ERR_INVALID, "ptx_bvh_build_gpu: null argument or max_leaf_size 0");
+	auto* b = new PtxBvh();
+	if (int rc = build_bvh_gpu(device, boxes, n, max_leaf_size, b->bvh, b->built_on_device)) {
+		delete b;
+		return rc;
+	}
+	*out = b;
+	return PTX_OK;
+}
+
+int ptx_bvh_build_triangles_gpu(int device, const float* verts, uint32_t n_verts, const uint32_t* indices, uint32_t n_tris, uint32_t max_leaf_size,
+                                ptx_bvh_t* out) {
+	if (!out || (n_tris && (!verts || !indices)) || max_leaf_size == 0) return fail(PTX_ERR_INVALID, "ptx_bvh_build_triangles_gpu: null argument or max_leaf_size 0");
+	for (uint64_t i = 0; i < uint64_t(n_tris) * 3; i++)
+		if (indices[i] >= n_verts) return fail(PTX_ERR_INVALID, "triangle index out of range");
+	std::vector<float> boxes;
+	triangle_boxes(verts, indices, n_tris, boxes);
+	return ptx_bvh_build_gpu(device, boxes.data(), n_tris, max_leaf_size, out);
+}
+
+int ptx_bvh_built_on_device(ptx_bvh_t b) { return b && b->built_on_device ? 1 : 0; }
 
 uint32_t ptx_bvh_num_nodes(ptx_bvh_t b) { return b ? uint32_t(b->bvh.nodes.size()) : 0; }
 uint32_t ptx_bvh_num_prims(ptx_bvh_t b) { return b ? uint32_t(b->bvh.order.size()) : 0; }

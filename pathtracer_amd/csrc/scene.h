@@ -73,6 +73,7 @@ int scene_counter_block(PtxScene* s, unsigned long long** out);
 
 struct PtxBvh {
 	ptx::HostBvh bvh;
+	bool built_on_device = false;
 };
 
 struct PtxScene {

@@ -85,3 +85,29 @@ def test_million_triangle_soup_and_traversal():
     host = capi.Bvh(verts=verts, indices=idx, max_leaf_size=4)
     gpu = capi.Bvh(verts=verts, indices=idx, max_leaf_size=4, gpu_device=0)
     same_tree(host, gpu)
+
+
+def test_gpu_builder_against_the_reference_builder_fixtures():
+    """Node arrays the reference's own BVH<Triangle>::build produced (tests/golden/builder.npz, builder2.npz: length,
+    first 64 nodes, SHA-256 of the whole array) for its fuzz mesh, sphere meshes, a 20k soup and the cow."""
+    import hashlib
+    from test_oracle_golden import load, positions_to_verts, sphere5_mesh
+    f, s = load("hits_fuzz462.npz"), load("hits_sphere3.npz")
+    verts_f = positions_to_verts(f["positions"])
+    cases = [
+        (load("builder.npz"), "fuzz462", (verts_f, np.arange(len(verts_f), dtype=np.uint32).reshape(-1, 3))),
+        (load("builder.npz"), "sphere3", (s["verts"], s["indices"])),
+        (load("builder.npz"), "soup20k", synth.soup(20000)),
+        (load("builder2.npz"), "cow", scenes.cow_mesh()),
+        (load("builder2.npz"), "sphere5", sphere5_mesh()[:2]),
+    ]
+    on_device = 0
+    for g, name, (verts, idx) in cases:
+        b = capi.Bvh(verts=verts, indices=idx, max_leaf_size=4, gpu_device=0)
+        nodes = b.nodes()
+        on_device += b.built_on_device
+        assert len(nodes) == int(g[f"{name}_n_nodes"]), name
+        assert nodes[:64].tobytes() == g[f"{name}_nodes_head"].tobytes(), name
+        assert hashlib.sha256(nodes.tobytes()).digest() == g[f"{name}_nodes_sha256"].tobytes(), name
+        b.close()
+    assert on_device >= 3      # meshes with a negative zero among their coordinates are built on the host by design

@@ -153,8 +153,43 @@ __device__ __forceinline__ void block_append(bool keep, uint32_t value, uint32_t
 	if (keep) list[wave_base[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
+// Two appends at once (the shade stage's survivors and its direct rays): one pair of barriers for both, and the two
+// atomics are in flight together.
+template<int WAVES>
+__device__ __forceinline__ void block_append2(bool keep_a, uint32_t* list_a, uint32_t* count_a, bool keep_b, uint32_t* list_b, uint32_t* count_b, uint32_t value) {
+	__shared__ uint32_t wave_base[2][WAVES];
+	const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const unsigned long long mask_a = __ballot(keep_a), mask_b = __ballot(keep_b);
+	if (lane == 0) wave_base[0][wave] = uint32_t(__popcll(mask_a)), wave_base[1][wave] = uint32_t(__popcll(mask_b));
+	__syncthreads();
+	if (threadIdx.x < 64) {
+		const uint32_t ca = lane < WAVES ? wave_base[0][lane] : 0u, cb = lane < WAVES ? wave_base[1][lane] : 0u;
+		uint32_t ia = ca, ib = cb;
+		for (int d = 1; d < WAVES; d <<= 1) {
+			const uint32_t oa = __shfl_up(ia, d), ob = __shfl_up(ib, d);
+			if (int(lane) >= d) ia += oa, ib += ob;
+		}
+		const uint32_t total_a = __shfl(ia, WAVES - 1), total_b = __shfl(ib, WAVES - 1);
+		uint32_t base = 0;
+		if (lane == 0 && total_a) base = atomicAdd(count_a, total_a);
+		if (lane == 1 && total_b) base = atomicAdd(count_b, total_b);
+		const uint32_t base_a = __shfl(base, 0), base_b = __shfl(base, 1);
+		if (lane < WAVES) wave_base[0][lane] = base_a + ia - ca, wave_base[1][lane] = base_b + ib - cb;
+	}
+	__syncthreads();
+	const unsigned long long below = (1ull << lane) - 1ull;
+	if (keep_a) list_a[wave_base[0][wave] + __popcll(mask_a & below)] = value;
+	if (keep_b) list_b[wave_base[1][wave] + __popcll(mask_b & below)] = value;
+}
+
 constexpr int RAYGEN_BLOCK = 1024;
-constexpr int SHADE_BLOCK = 1024;
+// The shade stage at 92-102 VGPRs fits one 1024-thread block per CU, and the CU would idle while that block waits at
+// its barriers and for its atomics; two 512-thread blocks overlap (measured: 6 % of a whole render; 256-thread blocks
+// lose part of it again to the queue at the list counter).
+#ifndef PTX_SHADE_BLOCK
+#define PTX_SHADE_BLOCK 512
+#endif
+constexpr int SHADE_BLOCK = PTX_SHADE_BLOCK;
 
 // Camera::sample_ray for samples k0 .. k0 + group - 1 of every slot that has them (pathtracer.cpp:448-454).
 __global__ void __launch_bounds__(RAYGEN_BLOCK) k_raygen(RenderBuffers rb, uint32_t k0, CameraRec cam, uint32_t key0, uint32_t key1,
@@ -441,8 +476,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 			for (uint32_t li = 0; li < sh.n_delta_lights; li++) rb.shadow_add[size_t(path) * sh.n_delta_lights + li] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		if (L_loaded) rb.rad[path] = make_float4(L.x, L.y, L.z, 0.0f);   // folded into the slot's sum in sample order by k_sum_pass
 	}
-	block_append<SHADE_BLOCK / 64>(alive, path, next_list, next_count);
-	block_append<SHADE_BLOCK / 64>(wants_direct, path, rb.direct, rb.counts + 2);
+	block_append2<SHADE_BLOCK / 64>(alive, next_list, next_count, wants_direct, rb.direct, rb.counts + 2, path);
 }
 
 // The shadow rays k_shade left, as a ray source / answer sink of the occlusion kernels: item k is light k % n_lights

@@ -479,8 +479,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 	block_append2<SHADE_BLOCK / 64>(alive, next_list, next_count, wants_direct, rb.direct, rb.counts + 2, path);
 }
 
-// The shadow rays k_shade left, as a ray source / answer sink of the occlusion kernels: item k is light k % n_lights
-// of the path list[k / n_lights]; entries whose light does not take part carry no ray.
+// The shadow rays k_shade left, as a ray source / answer sink of the occlusion kernels: item k is light k / n_paths
+// of the path list[k % n_paths]; entries whose light does not take part carry no ray.
 struct ShadowIO {
 	RenderBuffers rb;
 	const uint32_t* list;
@@ -492,7 +492,9 @@ struct ShadowIO {
 		r = Ray3{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 	}
 	__device__ __forceinline__ bool fetch(uint64_t item, Ray3& r, uint32_t& out) const {
-		out = list[item / rb.n_lights] * rb.n_lights + uint32_t(item % rb.n_lights);
+		// light by light over the active paths: neighbouring lanes then hold rays from neighbouring pixels to one light
+		const uint32_t n = *n_paths;
+		out = list[item % n] * rb.n_lights + uint32_t(item / n);
 		if (rb.shadow_add[out].w == 0.0f) return false;
 		load(out, r);
 		return true;

@@ -400,7 +400,7 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 		for (int k = 0; k < 9; k++) tot[k] += h[16 + k];
 		static const int every = getenv("PTX_PROFILE_EVERY") ? std::max(1, atoi(getenv("PTX_PROFILE_EVERY"))) : 200;
 		if (++launches % every == 0)
-			std::fprintf(stderr, "[scene lanes] iterations %llu | walk %llu x %.1f | tri %llu x %.1f | exit %llu x %.1f | enter %llu x %.1f\n", tot[0], tot[1],
+			std::fprintf(stderr, "[scene lanes any=%d] iterations %llu | walk %llu x %.1f | tri %llu x %.1f | exit %llu x %.1f | enter %llu x %.1f\n", int(ANY), tot[0], tot[1],
 			             double(tot[2]) / double(tot[1] ? tot[1] : 1), tot[3], double(tot[4]) / double(tot[3] ? tot[3] : 1), tot[5], double(tot[6]) / double(tot[5] ? tot[5] : 1), tot[7],
 			             double(tot[8]) / double(tot[7] ? tot[7] : 1));
 	}

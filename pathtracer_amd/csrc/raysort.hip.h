@@ -24,17 +24,20 @@
 
 namespace ptx {
 
-constexpr uint32_t SORT_GRID_BITS = 5;                     // 32 cells per axis
+#ifndef PTX_SORT_GRID_BITS
+#define PTX_SORT_GRID_BITS 5
+#endif
+constexpr uint32_t SORT_GRID_BITS = PTX_SORT_GRID_BITS;    // 32 cells per axis
 constexpr uint32_t SORT_KEY_BITS = 3 * SORT_GRID_BITS + 3; // 18
-constexpr uint32_t SORT_DIGIT_BITS = 9, SORT_DIGITS = 1u << SORT_DIGIT_BITS;
+constexpr uint32_t SORT_DIGIT_BITS = (SORT_KEY_BITS + 1) / 2, SORT_DIGITS = 1u << SORT_DIGIT_BITS;
 constexpr uint32_t SORT_TILE = 16384;                      // rays per block and pass
-static_assert(SORT_KEY_BITS == 2 * SORT_DIGIT_BITS, "two passes cover the key");
+static_assert(SORT_KEY_BITS <= 2 * SORT_DIGIT_BITS, "two passes cover the key");
 
-__device__ __forceinline__ uint32_t spread3(uint32_t v) {   // 5 bits -> every third bit
-	v &= 0x1Fu;
-	v = (v | (v << 8)) & 0x100Fu;
-	v = (v | (v << 4)) & 0x10C3u;
-	v = (v | (v << 2)) & 0x1249u;
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {   // up to 8 bits -> every third bit
+	v &= 0xFFu;
+	v = (v | (v << 8)) & 0x00F00Fu;
+	v = (v | (v << 4)) & 0x0C30C3u;
+	v = (v | (v << 2)) & 0x249249u;
 	return v;
 }
 

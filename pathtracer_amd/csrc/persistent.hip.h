@@ -38,12 +38,18 @@ constexpr unsigned long long WAVE_CHUNK = 64;     // consecutive ray slots a wav
 // The culled-order instance needs 82 VGPRs left alone, two above the 80 that let six waves share a
 // SIMD; held to 80 it runs 2 % faster on grouped rays (measured), the few spilled values being cold.
 // WIDE: walk the four-wide form of the tree (SceneRec::nodes4; culled order only).
-template<int MODE, bool ANY, bool WIDE = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? PTX_WIDE_WAVES : 6, WIDE ? PTX_WIDE_WAVES : 6))) k_mesh_persistent(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n, PtxHit* __restrict__ hits,
+// ZERO: the second pass, over the rays the first one set aside (`order` is that list, *n_dev its length): rays with
+// direction components that are exactly zero (orthographic views, straight-down shadow rays) are walked here with the
+// zero-aware slab tests of traverse.hip.h -- a kernel of its own, so the first pass carries none of that code.
+template<int MODE, bool ANY, bool WIDE = false, bool ZERO = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? PTX_WIDE_WAVES : (ZERO ? 5 : 6), WIDE ? PTX_WIDE_WAVES : (ZERO ? 5 : 6)))) k_mesh_persistent(SceneRec sc, const PtxRay* __restrict__ rays, uint64_t n_rays, PtxHit* __restrict__ hits,
                                                          float* __restrict__ bary, uint32_t* __restrict__ inst, uint8_t* __restrict__ occluded,
                                                          unsigned long long* __restrict__ next_ray, const int refill_min_idle,
                                                          const uint32_t* __restrict__ order, uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count,
-                                                         const int tri_min_lanes, const int stuck_max_lanes, const unsigned long long wave_chunk) {
+                                                         const int tri_min_lanes, const int stuck_max_lanes, const unsigned long long wave_chunk, const uint32_t* __restrict__ n_dev) {
+	static_assert(!(WIDE && ZERO), "the four-wide step has no zero-aware form");
+	const uint64_t n = ZERO ? uint64_t(*n_dev) : n_rays;
+	if (ZERO && n == 0) return;   // nothing was set aside: the usual case
 	const MeshRec mesh = sc.meshes[0];
 	const TriGeom* __restrict__ tris = sc.tris + mesh.tri_base;
 	const Node2* __restrict__ nodes = sc.nodes + mesh.node_base;
@@ -132,14 +138,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 					const float4* rp = reinterpret_cast<const float4*>(rays + idx);
 					const float4 a = rp[0], b = rp[1];
 					r = Ray3{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-					if (ray_in_fast_range(r)) {
+					if (ZERO ? ray_in_fast_range_z(r) : ray_in_fast_range(r)) {
 						// BVH::hit seeds the running Trace with hit = false, distance = inf (bvh.cpp:257-259)
 						cur.hit = false, cur.distance = INFINITY, cur.prim = 0xFFFFFFFFu;
-						inv.yx = refined_rcp(r.dx), inv.yy = refined_rcp(r.dy), inv.yz = refined_rcp(r.dz);
+						if (ZERO) inv.yx = slab_rcp(r.dx), inv.yy = slab_rcp(r.dy), inv.yz = slab_rcp(r.dz);
+						else inv.yx = refined_rcp(r.dx), inv.yy = refined_rcp(r.dy), inv.yz = refined_rcp(r.dz);
 						float tn;
 						sp = 0;
 						tri_k = 0;
-						if (slab_test<true>(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], r, inv, tn))
+						if (slab_test<true, ZERO>(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], r, inv, tn))
 							ref = WIDE ? mesh.root4_ref : mesh.root_ref;
 						else
 							ref = REF_DONE;
@@ -175,7 +182,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 							const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
 							const float4 n0 = p[0], n1 = p[1], n2 = p[2];
 							const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
-							node_decide<MODE, ANY, true, true>(n0, n1, n2, kids, r, inv, st, 0, sp, ref, cur.hit, cur.distance);
+							node_decide<MODE, ANY, true, true, ZERO>(n0, n1, n2, kids, r, inv, st, 0, sp, ref, cur.hit, cur.distance);
 						}
 					}
 				}
@@ -218,7 +225,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 #endif
 		if (on_node != 0ull) {
 			if (!(ref & REF_LEAF)) {
-				node_step<MODE, ANY, true, false>(nodes, r, inv, st, 0, sp, ref, cur.hit, cur.distance, nullptr);
+				node_step<MODE, ANY, true, false, ZERO>(nodes, r, inv, st, 0, sp, ref, cur.hit, cur.distance, nullptr);
 				tri_k = 0;
 			}
 		}

@@ -531,7 +531,7 @@ int scene_scratch(PtxScene* s, int slot, size_t bytes) {
 int scene_counter_block(PtxScene* s, unsigned long long** out) {
 	if (!s->next_ray) {
 		void* p = nullptr;
-		PTX_HIP(hipMalloc(&p, COUNTER_BLOCK_BYTES));
+		PTX_HIP(hipMalloc(&p, 2 * COUNTER_BLOCK_BYTES));   // one block per pass of a replenishing launch
 		s->allocations.push_back(p);
 		s->next_ray = static_cast<unsigned long long*>(p);
 	}
@@ -552,7 +552,8 @@ static void sort_table_shape(uint64_t n, uint32_t& n_tiles, uint32_t& n_chunks, 
 // ordinary entry points, slices of the fixed device array for the allocation-free one.
 struct PersistentBuffers {
 	unsigned long long* counters;   // COUNTER_BLOCK_BYTES, zeroed by the launch
-	uint32_t* slow_list;            // n entries: rays deferred to the plain-division kernel
+	uint32_t* slow_list;            // n entries: rays the first pass sets aside
+	uint32_t* slow_list2;           // n entries: rays the second (zero-aware) pass leaves to the plain-division kernel; null: no second pass
 	uint32_t* keys;                 // 2n: keys, keys after pass 0          (grouping pass only)
 	uint32_t* idx;                  // 2n: indices after pass 0, final order (grouping pass only)
 	uint32_t* table;                // table_len + n_chunks of sort_table_shape(n)
@@ -612,6 +613,8 @@ static int scene_persistent_buffers(PtxScene* s, bool sort, uint64_t n, Persiste
 	if (int rc = scene_counter_block(s, &pb.counters)) return rc;
 	if (int rc = grow_scratch(s, 7, n * sizeof(uint32_t))) return rc;
 	pb.slow_list = static_cast<uint32_t*>(s->scratch[7]);
+	if (int rc = grow_scratch(s, 8, n * sizeof(uint32_t))) return rc;
+	pb.slow_list2 = static_cast<uint32_t*>(s->scratch[8]);
 	return PTX_OK;
 }
 
@@ -623,7 +626,7 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const Persiste
 	if (wants_grouping(sort, n))
 		if (int rc = sort_rays(s, d_rays, n, pb, &order)) return rc;
 	unsigned long long* const next_ray = pb.counters;
-	PTX_HIP(hipMemsetAsync(next_ray, 0, COUNTER_BLOCK_BYTES, s->stream));
+	PTX_HIP(hipMemsetAsync(next_ray, 0, (pb.slow_list2 ? 2 : 1) * COUNTER_BLOCK_BYTES, s->stream));
 	uint32_t* slow_list = pb.slow_list;
 	uint32_t* slow_count = reinterpret_cast<uint32_t*>(next_ray) + 16;   // same zeroed block, its own 64-byte line
 	// enough 256-thread blocks to fill every CU at 8 waves per SIMD; each wave pulls rays until the pool is dry
@@ -648,9 +651,9 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const Persiste
 	// soup (half the loop iterations, but the same number of box tests and L1 accesses per ray, 8 more registers and
 	// therefore one wave per SIMD fewer), so it is off unless asked for.
 	static const bool wide = getenv("PTX_WIDE_TREE") && atoi(getenv("PTX_WIDE_TREE")) != 0;
-	if (culled && wide && s->rec.nodes4) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
-	else if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
-	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk);
+	if (culled && wide && s->rec.nodes4) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk, nullptr);
+	else if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk, nullptr);
+	else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray, refill, order, slow_list, slow_count, tri_min, stuck_max, wave_chunk, nullptr);
 	if (pb.timed) {
 		PTX_HIP(hipEventRecord(s->t_stop[slot], s->stream));
 		s->timed_launches++;
@@ -664,6 +667,15 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const Persiste
 		             double(h[17]) / double(h[19] ? h[19] : 1), h[20], double(h[18]) / double(h[20] ? h[20] : 1), double(h[21]) / double(h[16] ? h[16] : 1));
 	}
 #endif
+	// Second pass: the rays set aside walk the same kernel in its zero-aware form (most of them have a direction
+	// component that is exactly zero); what that pass cannot take either goes to the plain-division kernel.
+	if (pb.slow_list2) {
+		unsigned long long* const next_ray2 = next_ray + COUNTER_BLOCK_BYTES / sizeof(unsigned long long);
+		uint32_t* slow_count2 = reinterpret_cast<uint32_t*>(next_ray2) + 16;
+		if (culled) hipLaunchKernelGGL((k_mesh_persistent<MODE_CULLED, ANY, false, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray2, refill, slow_list, pb.slow_list2, slow_count2, tri_min, stuck_max, wave_chunk, slow_count);
+		else hipLaunchKernelGGL((k_mesh_persistent<MODE_REFERENCE, ANY, false, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst, d_occ, next_ray2, refill, slow_list, pb.slow_list2, slow_count2, tri_min, stuck_max, wave_chunk, slow_count);
+		slow_list = pb.slow_list2, slow_count = slow_count2;
+	}
 	const dim3 dgrid(uint32_t(std::min<uint64_t>(want, 1024)));
 	if (culled) hipLaunchKernelGGL((k_mesh_deferred<MODE_CULLED, ANY>), dgrid, block, 0, s->stream, s->rec, d_rays, slow_list, slow_count, d_hits, d_bary, d_inst, d_occ);
 	else hipLaunchKernelGGL((k_mesh_deferred<MODE_REFERENCE, ANY>), dgrid, block, 0, s->stream, s->rec, d_rays, slow_list, slow_count, d_hits, d_bary, d_inst, d_occ);
@@ -1042,7 +1054,7 @@ int ptx_trace_closest_noalloc(ptx_scene_t s, const PtxRay* rays, uint64_t n, Ptx
 	if (use_persistent(s) && !(flags & PTX_NO_PERSISTENT)) {
 		unsigned char* base = s->noalloc_scratch;   // device address from hipGetSymbolAddress, not the array's name
 		if (!base) return fail(PTX_ERR_UNSUPPORTED, "ptx_trace_closest_noalloc: no fixed scratch array on this device");
-		PersistentBuffers pb;
+		PersistentBuffers pb{};   // no second list: this entry point keeps to its fixed array (zero-direction rays go to the plain-division kernel)
 		pb.counters = reinterpret_cast<unsigned long long*>(base);
 		pb.slow_list = reinterpret_cast<uint32_t*>(base + NOALLOC_OFF_SLOW);
 		pb.keys = reinterpret_cast<uint32_t*>(base + NOALLOC_OFF_KEYS);

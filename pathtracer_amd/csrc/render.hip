@@ -6,18 +6,20 @@
 // Here every pixel of every tile in the batch is a SLOT.  For sample k of the tiles, all
 // slots run in lock step through
 //
-//   raygen  -> [ extend -> shade/scatter -> compact ] x (max_ray_depth + 1) -> add to slot sum
+//   raygen  -> [ extend -> shade/scatter/compact [-> shadow pass -> apply] ] x (max_ray_depth + 1) -> add to slot sum
 //
 //   raygen   camera ray per slot (Camera::sample_ray, 2 draws), every slot into the active list
-//   extend   closest hit of each active path's main ray and, when it has one, its direct ray
-//   shade    uses the two hits: adds the direct ray's emission, shades the main ray's vertex
-//            (emission, delta lights with inline occlusion queries, BSDF scatter twice), writes
-//            the next main + direct rays; finished paths add their sample to the slot's float
-//            sum; surviving paths are appended to the next active list with one atomic per wave
-//            (ballot + prefix popcount)
+//   extend   closest hit of each active path's main ray and of the direct rays the shade stage asked for
+//   shade    uses the two hits: adds the direct ray's emission, shades the main ray's vertex (emission, BSDF scatter
+//            twice, the delta lights' shadow rays and what each light would add), writes the next main + direct
+//            rays; surviving paths and wanted direct rays are appended to their lists with one atomic per block
+//            (ballot + prefix popcount + one LDS exchange)
+//   shadow   (scenes with point / spot / directional lights) any-hit queries for the shadow rays, then the unoccluded
+//            lights' contributions are added in light order
+//   Rays whose answer cannot reach the image are not traced (see PTX_RENDER_TRACE_UNUSED_RAYS in ptx.h).
 //
-// Samples of a slot are added in sample order (sample k is complete before k+1 starts), so a
-// slot's float sum is the same sequence of additions as the reference's tile-private
+// Samples of a slot are added in sample order (k_sum_pass folds a pass's samples into the slot's float sum in
+// sample order), so a slot's float sum is the same sequence of additions as the reference's tile-private
 // HDR_Image pixel (pathtracer.cpp:447-470).  When the tile's samples are done the sum goes to
 // the 40.24 fixed-point accumulator exactly as Pathtracer::accumulate does
 // (pathtracer.cpp:407-427); integer atomics make tiles that share pixels commute.

@@ -92,8 +92,8 @@ struct PtxScene {
 	uint64_t bytes_nodes = 0, bytes_tris = 0;
 	PtxCounters counters{};
 	// Scratch grown on demand (host-pointer calls, render state).
-	void* scratch[8] = {};
-	size_t scratch_bytes[8] = {};
+	void* scratch[10] = {};
+	size_t scratch_bytes[10] = {};
 	// Device-side timing of the dominant traversal kernel: HIP events recorded on the scene's
 	// stream right before and after each launch, kept in a ring (ptx_get_kernel_times).
 	static constexpr uint32_t TIMING_RING = 64;

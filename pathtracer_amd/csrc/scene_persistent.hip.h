@@ -1,4 +1,4 @@
-// scene_persistent.hip.h -- closest-hit queries against a two-level scene (instances over meshes
+// scene_persistent.hip.h -- closest-hit and occlusion queries against a two-level scene (instances over meshes
 // and analytic spheres) with wave-level ray replenishment and phase parking.
 //
 // Aggregate::hit over BVH<Instance> (aggregate.h:41-43) -> Instance::hit (instance.h:32-40) ->
@@ -82,19 +82,39 @@ struct BatchAnyIO {   // ptx_trace_any on a general scene: `scene.hit(shadow_ray
 	__device__ __forceinline__ void store(uint32_t out, const SceneHit& h) const { occluded[out] = h.hit ? 1 : 0; }
 };
 
+// The rays a first pass set aside, as the ray source of the second (zero-aware) pass: item k is ray list[k] of `io`.
+template<typename IO>
+struct ListIO {
+	IO io;
+	const uint32_t* list;
+	const uint32_t* n;
+	__device__ __forceinline__ uint64_t count() const { return *n; }
+	__device__ __forceinline__ void load(uint32_t out, Ray3& r) const { io.load(out, r); }
+	__device__ __forceinline__ bool fetch(uint64_t item, Ray3& r, uint32_t& out) const {
+		out = list[item];
+		io.load(out, r);
+		return true;
+	}
+	__device__ __forceinline__ void store(uint32_t out, const SceneHit& h) const { io.store(out, h); }
+};
+
 // Registers, not LDS, decide how many waves share a SIMD here.  With the world ray (while the lane is
 // inside an instance) and the once-per-ray bookkeeping kept in LDS the kernel fits 96 VGPRs without
 // spilling: five waves per SIMD, five 31 KB blocks per CU.  (At the 117 VGPRs of the all-in-registers
 // version only four fit; the same render took 11 % longer.)
 // ANY: occlusion queries.  A ray is finished by the first primitive it hits inside its distance bounds, subtrees
 // are skipped against the ray's far bound instead of a running closest hit, and only the hit flag is stored.
-template<typename IO, bool ANY = false>
+// ZERO: the second pass, over the rays the first one set aside: world or object-space rays with direction components
+// that are exactly zero are walked with the zero-aware slab tests of traverse.hip.h (a kernel of its own, so the
+// first pass carries none of that code).
+template<typename IO, bool ANY = false, bool ZERO = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_scene_persistent(SceneRec sc, IO io, unsigned long long* __restrict__ next_item, uint32_t* __restrict__ slow_list,
                                                           uint32_t* __restrict__ slow_count, const int refill_min, const unsigned long long wave_chunk, const int walk_steps) {
 	constexpr int MODE = MODE_CULLED;
 	const unsigned lane = threadIdx.x & 63u;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
 	const uint64_t n_items = io.count();
+	if (ZERO && n_items == 0) return;   // nothing was set aside: the usual case
 
 	__shared__ uint32_t lds_ref[SCENE_LDS_SLOTS * 256];
 	__shared__ float lds_tnear[SCENE_LDS_SLOTS * 256];
@@ -127,6 +147,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 	unsigned long long prof[9] = {};
 #endif
 
+	auto in_range = [](const Ray3& x) { return ZERO ? ray_in_fast_range_z(x) : ray_in_fast_range(x); };
+	auto rcp = [](float d) { return ZERO ? slab_rcp(d) : refined_rcp(d); };
 	// At the top level a leaf reference names the instance to visit next (its first) and how many of the
 	// leaf's instances are left, that one included.  Empty leaves are skipped.
 	auto settle_top = [&]() {
@@ -137,7 +159,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 		if (level == 1u) {   // back from an instance: the world ray returns from LDS
 			const float4 a = lds_world_ray[threadIdx.x], b = lds_world_ray[256 + threadIdx.x];
 			cr = Ray3{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-			cinv.yx = refined_rcp(cr.dx), cinv.yy = refined_rcp(cr.dy), cinv.yz = refined_rcp(cr.dz);
+			cinv.yx = rcp(cr.dx), cinv.yy = rcp(cr.dy), cinv.yz = rcp(cr.dz);
 		}
 		level = 0, cnode_base = sc.top_node_base, base = 0;
 		if ((leaf & 15u) > 1u) {
@@ -209,16 +231,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 				const uint64_t item = b + __popcll(dry & lanes_below);
 				uint32_t out_index;
 				if (item < b + take && io.fetch(item, cr, out_index)) {
-					if (!bailed && ray_in_fast_range(cr)) {
+					if (!bailed && in_range(cr)) {
 						have_ray = true;
 						ledger[L_OUT] = out_index;
 						// Aggregate(BVH<Instance>)::hit starts from hit = false, distance = inf (bvh.cpp:257-259)
 						best_hit = false, best_distance = INFINITY;
 						ledger[L_T] = 0u, ledger[L_PRIM] = 0xFFFFFFFFu, ledger[L_INST] = 0xFFFFFFFFu, ledger[L_U] = 0u, ledger[L_V] = 0u;
-						cinv.yx = refined_rcp(cr.dx), cinv.yy = refined_rcp(cr.dy), cinv.yz = refined_rcp(cr.dz);
+						cinv.yx = rcp(cr.dx), cinv.yy = rcp(cr.dy), cinv.yz = rcp(cr.dz);
 						level = 0, cnode_base = sc.top_node_base, sp = 0, base = 0, pend = 0u;
 						float tn;
-						ref = slab_test<true>(sc.top_min[0], sc.top_min[1], sc.top_min[2], sc.top_max[0], sc.top_max[1], sc.top_max[2], cr, cinv, tn) ? sc.top_ref : REF_DONE;
+						ref = slab_test<true, ZERO>(sc.top_min[0], sc.top_min[1], sc.top_min[2], sc.top_max[0], sc.top_max[1], sc.top_max[2], cr, cinv, tn) ? sc.top_ref : REF_DONE;
 						settle_top();
 					} else {
 						slow_list[atomicAdd(slow_count, 1u)] = out_index;   // finished by the one-ray-per-lane kernel with plain divisions
@@ -261,7 +283,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 				if (have_ray && !(ref & REF_LEAF)) {
 					const bool run_hit = level ? mh.hit : best_hit;
 					const float run_dist = level ? mh.distance : best_distance;
-					node_step<MODE, ANY, true, false>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
+					node_step<MODE, ANY, true, false, ZERO>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
 					if (level == 0u) settle_top();
 				}
 			}
@@ -312,7 +334,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 					}
 				} else {
 					const MeshRec& mesh = sc.meshes[in.mesh];
-					if (mesh.is_list || !mesh.tame || !ray_in_fast_range(r)) {
+					if (mesh.is_list || !mesh.tame || !in_range(r)) {
 						// outside what this kernel handles exactly: hand the whole ray to the plain kernel
 						slow_list[atomicAdd(slow_count, 1u)] = ledger[L_OUT];
 						have_ray = false, ref = REF_DONE, pend = 0u, level = 0u;
@@ -320,9 +342,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 						// BVH<Triangle>::hit (bvh.cpp:246-270): running Trace starts at hit = false, distance = inf
 						mh.hit = false, mh.distance = INFINITY, mh.prim = 0xFFFFFFFFu, mh.t = 0.0f, mh.u = mh.v = 0.0f;
 						RayInv rinv;
-						rinv.yx = refined_rcp(r.dx), rinv.yy = refined_rcp(r.dy), rinv.yz = refined_rcp(r.dz);
+						rinv.yx = rcp(r.dx), rinv.yy = rcp(r.dy), rinv.yz = rcp(r.dz);
 						float tn;
-						if (slab_test<true>(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], r, rinv, tn)) {
+						if (slab_test<true, ZERO>(mesh.root_min[0], mesh.root_min[1], mesh.root_min[2], mesh.root_max[0], mesh.root_max[1], mesh.root_max[2], r, rinv, tn)) {
 							lds_world_ray[threadIdx.x] = make_float4(cr.ox, cr.oy, cr.oz, cr.dx);
 							lds_world_ray[256 + threadIdx.x] = make_float4(cr.dy, cr.dz, cr.tmin, cr.tmax);
 							ledger[L_TOP_LEAF] = leaf;
@@ -380,8 +402,9 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 	if (int rc = scene_counter_block(s, &counters)) return rc;
 	if (int rc = scene_scratch(s, 7, size_t(max_items ? max_items : 1) * sizeof(uint32_t))) return rc;   // rays set aside for the plain kernel
 	uint32_t* slow_list = static_cast<uint32_t*>(s->scratch[7]);
+	if (int rc = scene_scratch(s, 8, size_t(max_items ? max_items : 1) * sizeof(uint32_t))) return rc;   // rays the second pass sets aside
 	uint32_t* slow_count = reinterpret_cast<uint32_t*>(counters) + 16;   // same zeroed block, its own 64-byte line
-	PTX_HIP(hipMemsetAsync(counters, 0, 256, s->stream));
+	PTX_HIP(hipMemsetAsync(counters, 0, 1024 + 256, s->stream));   // both passes' counters (the second pass uses the block's second half)
 	// Tuning knobs for experiments (not part of the ABI).
 	static const int blocks_per_cu = getenv("PTX_SCENE_BLOCKS_PER_CU") ? atoi(getenv("PTX_SCENE_BLOCKS_PER_CU")) : 5;
 	static const int refill_min = getenv("PTX_SCENE_REFILL_MIN_IDLE") ? atoi(getenv("PTX_SCENE_REFILL_MIN_IDLE")) : SCENE_REFILL_MIN_IDLE;
@@ -405,7 +428,14 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 			             double(tot[8]) / double(tot[7] ? tot[7] : 1));
 	}
 #endif
-	hipLaunchKernelGGL((k_scene_deferred<IO, ANY>), dim3(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, 256)))), block, 0, s->stream, s->rec, io, slow_list, slow_count);
+	// Second pass: the rays set aside walk the same kernel in its zero-aware form (most of them have a direction
+	// component that is exactly zero, in world space or inside an instance); what that pass cannot take either
+	// goes to the plain-division kernel.
+	uint32_t* slow_list2 = static_cast<uint32_t*>(s->scratch[8]);
+	unsigned long long* counters2 = counters + 128;   // the second half of the counter block
+	uint32_t* slow_count2 = reinterpret_cast<uint32_t*>(counters2) + 16;
+	hipLaunchKernelGGL((k_scene_persistent<ListIO<IO>, ANY, true>), grid, block, 0, s->stream, s->rec, ListIO<IO>{io, slow_list, slow_count}, counters2, slow_list2, slow_count2, refill_min, wave_chunk, walk_steps);
+	hipLaunchKernelGGL((k_scene_deferred<IO, ANY>), dim3(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, 256)))), block, 0, s->stream, s->rec, io, slow_list2, slow_count2);
 	return PTX_OK;
 }
 

@@ -94,17 +94,38 @@ __device__ __forceinline__ bool ray_in_fast_range(const Ray3& r) {
 	       tame_coord(r.oz);
 }
 
+// The same with direction components that are exactly zero allowed (orthographic views, straight-down shadow rays): the
+// ZERO instances of the tests below treat such an axis as the reference does (bbox.h:98-120).  A zero vector is no direction.
+__device__ __forceinline__ bool dir_component_ok_z(float d) { return d == 0.0f || exp_within(d, -40, 10); }
+__device__ __forceinline__ bool ray_in_fast_range_z(const Ray3& r) {
+	return dir_component_ok_z(r.dx) && dir_component_ok_z(r.dy) && dir_component_ok_z(r.dz) && !(r.dx == 0.0f && r.dy == 0.0f && r.dz == 0.0f) &&
+	       tame_coord(r.ox) && tame_coord(r.oy) && tame_coord(r.oz);
+}
+__device__ __forceinline__ bool ray_has_zero_component(const Ray3& r) { return r.dx == 0.0f || r.dy == 0.0f || r.dz == 0.0f; }
+
 struct RayInv {
 	float yx, yy, yz;   // refined reciprocals of the direction (FAST only)
 };
+// What RayInv holds for a direction component: the refined reciprocal, or +-inf for +-0 (v_rcp_f32's answer), with
+// which `numerator * y` is bit for bit the IEEE quotient numerator / +-0 (+-inf by the sign rules, NaN for 0 / 0).
+__device__ __forceinline__ float slab_rcp(float d) { return d == 0.0f ? __builtin_amdgcn_rcpf(d) : refined_rcp(d); }
 
 // BBox::hit(ray, times = (0, inf)) -- lib/bbox.h:81-154.  Returns the accept/reject decision;
 // `tnear` receives min_intersect (bbox.h:137), used only to order and cull in CULLED mode.
-template<bool FAST>
+// ZERO (with FAST): direction components may be exactly zero; `inv` then holds slab_rcp() of them.
+template<bool FAST, bool ZERO = false>
 __device__ __forceinline__ bool slab_test(float minx, float miny, float minz, float maxx, float maxy, float maxz, const Ray3& r,
                                           const RayInv& inv, float& tnear) {
 	float tx0, tx1, ty0, ty1, tz0, tz1;
-	if (FAST) {
+	if (FAST && ZERO) {
+		if (r.dx == 0.0f && (r.ox < minx || r.ox > maxx)) return false;   // bbox.h:98-106
+		if (r.dy == 0.0f && (r.oy < miny || r.oy > maxy)) return false;
+		if (r.dz == 0.0f && (r.oz < minz || r.oz > maxz)) return false;
+		// a zero axis: (plane - origin) / +-0 == (plane - origin) * +-inf; the others as below
+		tx0 = r.dx == 0.0f ? (minx - r.ox) * inv.yx : div_by(minx - r.ox, r.dx, inv.yx), tx1 = r.dx == 0.0f ? (maxx - r.ox) * inv.yx : div_by(maxx - r.ox, r.dx, inv.yx);
+		ty0 = r.dy == 0.0f ? (miny - r.oy) * inv.yy : div_by(miny - r.oy, r.dy, inv.yy), ty1 = r.dy == 0.0f ? (maxy - r.oy) * inv.yy : div_by(maxy - r.oy, r.dy, inv.yy);
+		tz0 = r.dz == 0.0f ? (minz - r.oz) * inv.yz : div_by(minz - r.oz, r.dz, inv.yz), tz1 = r.dz == 0.0f ? (maxz - r.oz) * inv.yz : div_by(maxz - r.oz, r.dz, inv.yz);
+	} else if (FAST) {
 		// direction components are non-zero here, so the dir == 0 rejects (bbox.h:98-106) cannot fire
 		tx0 = div_by(minx - r.ox, r.dx, inv.yx), tx1 = div_by(maxx - r.ox, r.dx, inv.yx);
 		ty0 = div_by(miny - r.oy, r.dy, inv.yy), ty1 = div_by(maxy - r.oy, r.dy, inv.yy);
@@ -143,7 +164,16 @@ __device__ __forceinline__ bool slab_test(float minx, float miny, float minz, fl
 // whenever the two approximations are further apart than 2^-20 of their magnitudes; otherwise the
 // lane reports `ambiguous` and the caller runs the exact test.  `tnear` is the approximate LO
 // (ordering and culling only, inside the guard band of cull_limit).
+//
+// ZERO: direction components may be exactly zero (inv holds slab_rcp() of them).  On such an axis the products below
+// ARE the reference's quotients: -inf / +inf when the origin lies strictly between the two planes (the axis then
+// constrains nothing, in the reference's compare-and-select sequence as in the min/max merges here), two infinities
+// of one sign when it lies outside (the reference rejects at once, bbox.h:98-106; here LO = +inf or HI = -inf, and
+// since some other axis is finite that rejects too), NaN when it lies ON a plane (0 / 0: what the reference's
+// sequence does with a NaN depends on its position, so the lane reports `ambiguous`).  An infinite LO or HI is a
+// certain reject, not a close call.
 constexpr float SLAB_AMBIGUITY = 0x1p-20f;
+template<bool ZERO = false>
 __device__ __forceinline__ bool slab_test_approx(float minx, float miny, float minz, float maxx, float maxy, float maxz, const Ray3& r, const RayInv& inv,
                                                  float& tnear, bool& ambiguous) {
 	const float ax = (minx - r.ox) * inv.yx, bx = (maxx - r.ox) * inv.yx;
@@ -151,7 +181,12 @@ __device__ __forceinline__ bool slab_test_approx(float minx, float miny, float m
 	const float az = (minz - r.oz) * inv.yz, bz = (maxz - r.oz) * inv.yz;
 	const float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
 	const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-	ambiguous = fabsf(hi - lo) <= SLAB_AMBIGUITY * (fabsf(lo) + fabsf(hi));
+	const float spread = fabsf(lo) + fabsf(hi);
+	ambiguous = fabsf(hi - lo) <= SLAB_AMBIGUITY * spread;
+	if (ZERO) {
+		ambiguous = ambiguous && spread < INFINITY;
+		ambiguous = ambiguous || ax != ax || bx != bx || ay != ay || by != by || az != az || bz != bz;
+	}
 	tnear = lo;
 	return lo <= hi && hi >= 0.0f;
 }
@@ -273,22 +308,22 @@ __device__ __forceinline__ void pop_ref(const Ray3& r, StackType& st, const int 
 // first three 16-byte pieces (left box, right box), kids its two child references.
 // DEFER_POP: when neither child is taken, leave REF_NONE in `ref` instead of popping, so that a caller
 // with other reasons to pop (a leaf it parks) runs one pop loop for all of them.
-template<int MODE, bool ANY, bool FAST, bool DEFER_POP = false, typename StackType>
+template<int MODE, bool ANY, bool FAST, bool DEFER_POP = false, bool ZERO = false, typename StackType>
 __device__ __forceinline__ void node_decide(const float4 n0, const float4 n1, const float4 n2, const uint2 kids, const Ray3& r, const RayInv& inv, StackType& st,
                                             const int base, int& sp, uint32_t& ref, bool run_hit, float run_dist) {
 	float tl, tr;
 	bool hl, hr;
 	if (FAST && MODE == MODE_CULLED) {
 		bool al, ar;
-		hl = slab_test_approx(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl, al);
-		hr = slab_test_approx(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr, ar);
+		hl = slab_test_approx<ZERO>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl, al);
+		hr = slab_test_approx<ZERO>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr, ar);
 		if (__builtin_expect(__any(al || ar), 0)) {   // a ray grazing a box within rounding: decide it exactly
-			if (al) hl = slab_test<true>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl);
-			if (ar) hr = slab_test<true>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr);
+			if (al) hl = slab_test<true, ZERO>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl);
+			if (ar) hr = slab_test<true, ZERO>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr);
 		}
 	} else {
-		hl = slab_test<FAST>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl);
-		hr = slab_test<FAST>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr);
+		hl = slab_test<FAST, FAST && ZERO>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl);
+		hr = slab_test<FAST, FAST && ZERO>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr);
 	}
 	if (MODE == MODE_REFERENCE) {
 		if (hl) {
@@ -367,7 +402,7 @@ __device__ __forceinline__ void node4_decide(const Node4* __restrict__ node, con
 	ref = n > 0 ? val[0] : REF_NONE;
 }
 
-template<int MODE, bool ANY, bool FAST, bool STATS, typename StackType>
+template<int MODE, bool ANY, bool FAST, bool STATS, bool ZERO = false, typename StackType>
 __device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const Ray3& r, const RayInv& inv, StackType& st, const int base, int& sp,
                                           uint32_t& ref, bool run_hit, float run_dist, TraverseStats* stats) {
 	const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
@@ -375,7 +410,7 @@ __device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const
 	const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
 	if (STATS) stats->nodes++;
 	if (STATS) stats->max_sp = max(stats->max_sp, uint32_t(sp - base));
-	node_decide<MODE, ANY, FAST>(n0, n1, n2, kids, r, inv, st, base, sp, ref, run_hit, run_dist);
+	node_decide<MODE, ANY, FAST, false, ZERO>(n0, n1, n2, kids, r, inv, st, base, sp, ref, run_hit, run_dist);
 }
 
 // A whole traversal: walk interior nodes until every lane of the wave holds a leaf (or is

@@ -174,3 +174,76 @@ def test_full_size_properties():
     assert bool((lost | (out[:, 1] != cul[:, 1]) | ~hit).all())
     assert bool((out[:, 0].view(torch.float32)[hit & ~lost] <= below[:, 7][hit & ~lost]).all())
     scene.close()
+
+
+def test_zero_direction_components_in_bulk(oracle):
+    """Batches of axis-aligned rays (orthographic views, straight-down shadow rays) -- direction components that are
+    exactly +0 or -0, one or two of them, origins inside, outside and exactly ON box planes (0/0 in BBox::hit,
+    bbox.h:98-120) -- walk the replenishing kernels' zero-aware second pass.  Mesh and instanced scene (axis-aligned
+    instance transforms keep the zeros in object space), every mode, against the checker: bit-exact."""
+    g = np.random.Generator(np.random.Philox(key=404))
+    n = 1 << 17
+    dirs = np.array([[0, -1, 0], [0, 1, 0], [1, 0, 0], [0, 0, -1], [-0.0, -1, 0], [0, -1, -0.0], [-0.0, 0, 1],
+                     [0.6, 0, -0.8], [0, 0.6, 0.8], [-0.8, -0.6, 0], [0.6, -0.0, 0.8]], dtype=np.float32)
+
+    def axis_rays(lo, hi, snap):
+        r = np.zeros(n, dtype=abi.RAY_DTYPE)
+        r["o"] = (lo - 0.2 * (hi - lo) + g.random((n, 3)) * 1.4 * (hi - lo)).astype(np.float32)
+        # a share of the origins sits exactly on coordinates that are box planes of the tree
+        k = n // 8
+        pick = g.integers(0, len(snap), (k, 3))
+        for a in range(3):
+            on = g.random(k) < 0.5
+            r["o"][:k, a] = np.where(on, snap[pick[:, a], a], r["o"][:k, a])
+        r["d"] = dirs[g.integers(0, len(dirs), n)]
+        r["tmin"], r["tmax"] = 0.0, np.inf
+        r["tmax"][::5] = np.float32(0.7) * np.float32(np.linalg.norm(hi - lo))
+        return r
+
+    verts, idx = synth.soup(30000, key=41, extent=4.0, half=0.1)
+    sb = abi.SceneBuilder()
+    md = sb.mesh_desc(verts, idx)
+    rays = axis_rays(verts[:, :3].min(0), verts[:, :3].max(0), verts[:, :3])
+    want_scene = oracle.mesh_scene(md)
+    want, want_any = want_scene.trace_closest(rays), want_scene.trace_any(rays)
+    scene = capi.Scene(mesh_desc=md, keep=sb)
+    for mode in MODES:
+        got = scene.trace_closest(rays, flags=mode)
+        assert np.array_equal(bits(got["hits"]["distance"]), bits(want["hits"]["distance"])) and np.array_equal(got["hits"]["prim"], want["hits"]["prim"]), f"mesh mode {mode}"
+        assert np.array_equal(scene.trace_any(rays, flags=mode), want_any), f"mesh occlusion mode {mode}"
+    scene.close()
+    assert 0.2 < (want["hits"]["prim"] != abi.PTX_NO_HIT).mean() < 0.999
+
+    # instanced: axis-aligned placements (translation, 90-degree turns, scale) keep zero components zero in object space
+    sb = abi.SceneBuilder()
+    m = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.5, 0.5, 0.5)))
+    soup = sb.add_mesh(*synth.soup(2000, key=42, extent=1.0, half=0.08))
+    q = sb.add_mesh(*scenes.quad())
+    ico = sb.add_mesh(*scenes.icosphere(2))
+    for k in range(27):
+        pos = (float(k % 3) * 1.5, float((k // 3) % 3) * 1.5, float(k // 9) * 1.5)
+        what = k % 4
+        if what == 0:
+            sb.add_instance(soup, m, scenes.trs(pos))
+        elif what == 1:
+            sb.add_instance(q, m, scenes.trs(pos, axis=(1, 0, 0), deg=0.0, scale=(0.7, 1.0, 0.5)))
+        elif what == 2:
+            sb.add_instance(ico, m, scenes.trs(pos, scale=(0.4, 0.6, 0.5)))
+        else:
+            sb.add_instance(-1, m, scenes.trs(pos, scale=(0.5, 0.5, 0.5)), sphere_radius=1.0)
+    desc = sb.desc()
+    lo, hi = np.array([-1.0, -1.0, -1.0]), np.array([4.5, 4.5, 4.5])
+    snap = np.array([[0.0, 0.0, 0.0], [1.5, 1.5, 1.5], [3.0, 3.0, 3.0], [0.7, 0.0, 0.5], [2.2, 1.5, 2.0]], dtype=np.float32)
+    rays = axis_rays(lo, hi, snap)
+    osc = oracle.scene(desc)
+    want, want_any = osc.trace_closest(rays), osc.trace_any(rays)
+    osc.close()
+    sc = capi.Scene(desc, keep=sb)
+    for mode in MODES:
+        got = sc.trace_closest(rays, flags=mode)
+        hit = want["hits"]["prim"] != abi.PTX_NO_HIT
+        assert np.array_equal(bits(got["hits"]["distance"]), bits(want["hits"]["distance"])) and np.array_equal(got["hits"]["prim"], want["hits"]["prim"]), f"scene mode {mode}"
+        assert np.array_equal(got["inst"][hit], want["inst"][hit])
+        assert np.array_equal(sc.trace_any(rays, flags=mode), want_any), f"scene occlusion mode {mode}"
+    sc.close()
+    assert 0.1 < hit.mean() < 0.999

@@ -30,6 +30,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "scene.h"
@@ -703,6 +705,8 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		const dim3 block(256), grid_slots((ns + 255) / 256), grid_items((2 * n_paths + 255) / 256);
 		// Small batches (a 256x256 film is 65k paths, 8 waves per CU) do not fill the replenishing kernel's
 		// waves for long enough to pay for its set-up launches: they keep one ray per lane.
+		static const bool count_rays = getenv("PTX_RENDER_COUNT_RAYS") && atoi(getenv("PTX_RENDER_COUNT_RAYS")) != 0;
+		uint64_t n_main_rays = 0, n_direct_rays = 0;
 		const bool reference_order = (flags & PTX_RENDER_REFERENCE_ORDER) != 0;
 		const bool trace_unused = (flags & PTX_RENDER_TRACE_UNUSED_RAYS) != 0;
 		ShadeTables shade_tables = s->shade;
@@ -720,6 +724,12 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 				// ray): no hit of theirs is used, only the direct rays are traced.
 				const bool last_vertex_round = round == cam->film_max_ray_depth && round > 0;
 				const RenderIO io{rb, rb.active[cur], rb.counts + cur, (last_vertex_round && !trace_unused) ? 0u : 1u};
+				if (count_rays) {   // diagnostic (PTX_RENDER_COUNT_RAYS=1): rays this round traces, read back with a stream sync
+					uint32_t c[3];
+					PTX_HIP(hipMemcpyAsync(c, rb.counts, sizeof(c), hipMemcpyDeviceToHost, s->stream));
+					PTX_HIP(hipStreamSynchronize(s->stream));
+					n_main_rays += io.main_rays ? c[cur] : 0u, n_direct_rays += c[2];
+				}
 				if (persistent) {
 					if (int rc = launch_scene_persistent(s, io, 2 * n_paths)) return rc;
 				} else if (reference_order) {
@@ -752,7 +762,12 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		}
 		hipLaunchKernelGGL(k_flush, grid_slots, block, 0, s->stream, rb, ns, d_accum, d_samples);
 		PTX_HIP(hipGetLastError());
-		for (const TileRec& t : chunk) s->counters.paths += uint64_t(t.w) * t.h * t.s_count;
+		uint64_t chunk_paths = 0;
+		for (const TileRec& t : chunk) chunk_paths += uint64_t(t.w) * t.h * t.s_count;
+		s->counters.paths += chunk_paths;
+		if (count_rays)
+			std::fprintf(stderr, "[render rays] %llu paths: %llu main rays, %llu direct rays traced (%.2f rays per path)\n", (unsigned long long)chunk_paths, (unsigned long long)n_main_rays,
+			             (unsigned long long)n_direct_rays, double(n_main_rays + n_direct_rays) / double(chunk_paths ? chunk_paths : 1));
 	}
 	if (host) {
 		PTX_HIP(hipMemcpyAsync(accum_rgb, d_accum, n_pixels * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));

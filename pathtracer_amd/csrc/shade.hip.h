@@ -173,7 +173,9 @@ __device__ __forceinline__ ScatterRec bsdf_scatter(const ShadeTables& sh, const 
 		const float phi = rng.next_unit() * 2.0f * SH_PI;
 		const float cos_t = sqrtf(rng.next_unit());
 		const float sin_t = sqrtf(1 - cos_t * cos_t);
-		ret.direction = v3(cosf(phi) * sin_t, cos_t, sinf(phi) * sin_t);
+		float sin_phi, cos_phi;
+		sincosf(phi, &sin_phi, &cos_phi);   // the same values as sinf / cosf, one argument reduction for both
+		ret.direction = v3(cos_phi * sin_t, cos_t, sin_phi * sin_t);
 		ret.attenuation = bsdf_evaluate(sh, m, ret.direction, u, v);
 		ret.specular = false;
 		break;

@@ -309,7 +309,7 @@ typedef struct PtxTile {                     /* Pathtracer::Tile, pathtracer.cpp
  * a path is the i-th number the reference's RNG::unit() would have produced on that path.
  * PtxTile::seed is ignored (it seeds the reference's per-tile mt19937).
  * Limits: film_max_ray_depth <= 8191 (PTX_ERR_UNSUPPORTED above); device memory 172 B per path in flight (at most
- * 64 M paths per pass) plus 49 B per path and point / spot / directional light.
+ * 128 M paths per pass) plus 49 B per path and point / spot / directional light.
  * Flags: PTX_MEM_DEVICE, PTX_ASYNC, PTX_NO_PERSISTENT, PTX_RENDER_REFERENCE_ORDER, PTX_RENDER_TRACE_UNUSED_RAYS. */
 int ptx_render_tiles(ptx_scene_t scene, const PtxCamera* camera, const PtxTile* tiles, uint32_t n_tiles, uint64_t seed,
                      int64_t* accum_rgb, uint32_t* samples, uint32_t flags);

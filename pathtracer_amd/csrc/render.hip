@@ -42,9 +42,12 @@
 namespace ptx {
 
 constexpr float RAY_MINIMUM_BOUND = 0.001f;   // pathtracer.cpp:17
-// Paths in flight per pass (172 B of state each: 11.5 GB at the limit).  Measured on a 268 M-path render:
-// 8 M paths per pass 0.67 s, 32 M 0.60 s, 128 M 0.59 s.
-constexpr uint64_t MAX_SLOTS_PER_CHUNK = 64u << 20;
+// Paths in flight per pass (172 B of state each: 23 GB at the limit).  Measured on a 268 M-path render (config 2):
+// 32 M paths per pass 0.348 s, 64 M 0.335 s, 128 M 0.331 s, 256 M 0.331 s.
+#ifndef PTX_MAX_PATHS_LOG2
+#define PTX_MAX_PATHS_LOG2 27
+#endif
+constexpr uint64_t MAX_SLOTS_PER_CHUNK = uint64_t(1) << PTX_MAX_PATHS_LOG2;
 
 struct alignas(16) SlotInfo {
 	uint32_t pixel, s_begin, s_count, pad;
@@ -658,6 +661,8 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 			if (per_sample >= (uint64_t(1) << 32)) return fail(PTX_ERR_UNSUPPORTED, "ptx_render_tiles: tiles x delta lights exceed 2^32 shadow rays per sample; pass fewer tiles per call");
 			group = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(group, (uint64_t(1) << 28) / per_sample)));
 		}
+		// passes of equal size: 64 samples in flight at most 63 at a time are two passes of 32, not 63 + 1
+		group = (max_samples + (max_samples + group - 1) / group - 1) / ((max_samples + group - 1) / group);
 		const uint64_t n_paths = n_slots * group;
 		RenderBuffers rb{};
 		rb.n_slots = ns, rb.group = group;

@@ -111,3 +111,11 @@ def test_gpu_builder_against_the_reference_builder_fixtures():
         assert hashlib.sha256(nodes.tobytes()).digest() == g[f"{name}_nodes_sha256"].tobytes(), name
         b.close()
     assert on_device >= 3      # meshes with a negative zero among their coordinates are built on the host by design
+
+
+def test_ten_million_boxes():
+    """The size of the 10M+ configuration: several thousand scan tiles, bin tables of millions of nodes per level."""
+    boxes = random_boxes(10_000_000, key=77, spread=100.0, size=0.05)
+    host = capi.Bvh(boxes=boxes, max_leaf_size=4)
+    gpu = capi.Bvh(boxes=boxes, max_leaf_size=4, gpu_device=0)
+    same_tree(host, gpu)

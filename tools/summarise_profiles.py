@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out", "prof")
 P = os.path.join(ROOT, "profiles")
 RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
-KERNEL = "k_mesh_persistent<1, false"      # <culled, closest[, binary tree]>
+KERNEL = "k_mesh_persistent<1, false, false, false>"      # <culled, closest, binary tree, first pass>
 N_RAYS = 16777216.0
 CUS = 256
 
@@ -117,6 +117,18 @@ if "SQ_INSTS_VALU" in cnt and "GRBM_GUI_ACTIVE" in cnt:
                        "(cycles per XCD) measured in the same pass; valu_lane_throughput_frac = SQ_THREAD_CYCLES_VALU / (256 CUs x 64 lanes x cycles)",
                "counters": cnt, "derived": d}, open(os.path.join(P, f"{RND}_pmc_closest.json"), "w"), indent=1)
     print("closest:", json.dumps(d, indent=1))
+
+# ---- the bench line's roofline block again, from the summaries just written (the run itself used the summaries
+# committed before it: same formulas, this run's counters), so that the line and the files beside it agree exactly
+line_path = os.path.join(P, f"{RND}_bench_line.json")
+if os.path.exists(line_path) and "SQ_INSTS_VALU" in cnt:
+    sys.path.insert(0, ROOT)
+    import bench
+    line = json.load(open(line_path))
+    old = line["roofline"]
+    line["roofline"] = bench.roofline_block(old["kernel_ms"], line["config"]["rays_per_gpu"], old["culled_traversal"],
+                                            old["reference_semantics_equiv"]["nodes_per_ray"], old["reference_semantics_equiv"]["tris_per_ray"])
+    json.dump(line, open(line_path, "w"), indent=1)
 
 # ---- render kernels
 rows = kernel_stats("r_trace", f"{RND}_kernel_stats_render.csv")

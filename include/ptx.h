@@ -15,7 +15,10 @@
  *    The library owns device memory reachable from a handle until *_destroy.
  *  - Output buffers are caller-allocated.  Pointers are host pointers unless the
  *    call's `flags` carry PTX_MEM_DEVICE, in which case rays/hits/accumulators are
- *    device pointers on the scene's device and nothing is copied.
+ *    device pointers on the scene's device and nothing is copied.  Host ray batches of
+ *    8 M rays and more are staged in chunks of about 4 M rays, the upload of one chunk
+ *    beside the traversal of the one before and the download of the one before that;
+ *    page-locked host buffers (hipHostMalloc, hipHostRegister) transfer fastest.
  *  - Calls are synchronous with respect to the host unless PTX_ASYNC is set, in
  *    which case work is only enqueued on the scene's stream (device pointers only).
  *  - A handle may be used by one host thread at a time; use one handle per GPU.

@@ -99,4 +99,8 @@ struct PtxScene {
 	static constexpr uint32_t TIMING_RING = 64;
 	hipEvent_t t_start[TIMING_RING] = {}, t_stop[TIMING_RING] = {};
 	uint64_t timed_launches = 0;
+	// Host-buffer ray queries in chunks (the upload of one chunk, the traversal of the one before and the
+	// download of the one before that overlap): two copy streams and the chunks' events, created on first use.
+	hipStream_t up_stream = nullptr, down_stream = nullptr;
+	std::vector<hipEvent_t> chunk_events;
 };

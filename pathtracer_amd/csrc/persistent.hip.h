@@ -99,6 +99,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 
 #ifdef PTX_PROFILE_LANES
 	unsigned long long prof_iters = 0, prof_node_lanes = 0, prof_tri_lanes = 0, prof_node_iters = 0, prof_tri_iters = 0, prof_busy = 0;
+	// 100 MHz clock: first wave start, first wave to find the pool dry, last wave out (minima kept as maxima of the complement)
+	if (lane == 0) atomicMax(next_ray + 22, ~(unsigned long long)wall_clock64());
 #endif
 	for (;;) {
 		// ---- replenish dry slots
@@ -121,6 +123,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 					}
 					if (++parts_dry == RAY_PARTS) {
 						pool_empty = true, chunk_next = chunk_end = 0;
+#ifdef PTX_PROFILE_LANES
+						if (lane == 0) atomicMax(next_ray + 23, ~(unsigned long long)wall_clock64());
+#endif
 						break;
 					}
 					part = (part + 1) % RAY_PARTS;
@@ -253,6 +258,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 	if (lane == 0) {
 		atomicAdd(next_ray + 16, prof_iters), atomicAdd(next_ray + 17, prof_node_lanes), atomicAdd(next_ray + 18, prof_tri_lanes);
 		atomicAdd(next_ray + 19, prof_node_iters), atomicAdd(next_ray + 20, prof_tri_iters), atomicAdd(next_ray + 21, prof_busy);
+		const unsigned long long t_out = wall_clock64();
+		atomicMax(next_ray + 24, t_out), atomicAdd(next_ray + 25, t_out & 0xFFFFFFFFFFull), atomicAdd(next_ray + 26, 1ull);
 	}
 #endif
 }

@@ -894,32 +894,54 @@ extern "C" int ptx_frame_reduce(ptx_frame_t dst, const ptx_frame_t* parts, uint3
 	PTX_HIP(hipSetDevice(dev));
 	const size_t bytes = dst->n_pixels * (3 * sizeof(int64_t) + sizeof(uint32_t));
 	const size_t a_bytes = dst->n_pixels * 3 * sizeof(int64_t);
-	void* staging = nullptr;   // one film's worth on the destination GPU, for parts that live on another GPU
 	const dim3 block(256), grid(uint32_t(std::min<size_t>((dst->n_pixels * 3 + 255) / 256, 256 * 64)));
-	int rc = PTX_OK;
-	for (uint32_t i = 0; i < n_parts && rc == PTX_OK; i++) {
-		const PtxFrame* p = parts[i];
-		const unsigned long long* src_acc = reinterpret_cast<const unsigned long long*>(p->accum);
-		const uint32_t* src_smp = p->samples;
-		hipError_t e = hipSuccess;
-		if (p->scene->device != dev) {
-			// the film is one allocation (sums, then counts): one copy over xGMI (or through the host where the
-			// two GPUs have no direct path -- hipMemcpyPeer takes care of either)
-			if (!staging) e = hipMalloc(&staging, bytes);
-			if (e == hipSuccess) e = hipMemcpyPeerAsync(staging, dev, p->accum, p->scene->device, bytes, stream);
-			src_acc = static_cast<const unsigned long long*>(staging);
-			src_smp = reinterpret_cast<const uint32_t*>(static_cast<const char*>(staging) + a_bytes);
-		}
-		if (e == hipSuccess) {
-			hipLaunchKernelGGL(k_frame_add, grid, block, 0, stream, reinterpret_cast<unsigned long long*>(dst->accum), src_acc, dst->samples, src_smp, dst->n_pixels);
-			e = hipGetLastError();
-		}
-		if (e == hipSuccess && staging) e = hipStreamSynchronize(stream);   // the staging film is reused by the next part
-		if (e != hipSuccess) rc = hip_fail(e, "ptx_frame_reduce");
+	auto add = [&](const void* film) -> hipError_t {
+		hipLaunchKernelGGL(k_frame_add, grid, block, 0, stream, reinterpret_cast<unsigned long long*>(dst->accum), static_cast<const unsigned long long*>(film), dst->samples,
+		                   reinterpret_cast<const uint32_t*>(static_cast<const char*>(film) + a_bytes), dst->n_pixels);
+		return hipGetLastError();
+	};
+	// Parts on the destination's own GPU are added where they lie.  Parts on other GPUs are copied into staging
+	// films on the destination first, a group of them at a time, each copy on a stream of its own: every source
+	// GPU has its own xGMI link to the destination, so the copies of a group run side by side (a film is one
+	// allocation, sums then counts: one copy; hipMemcpyPeer goes through the host where two GPUs have no direct path).
+	std::vector<const PtxFrame*> remote;
+	hipError_t e = hipSuccess;
+	// test switch: stage same-device parts too, so that one GPU exercises the copy path
+	const bool stage_all = getenv("PTX_FRAME_REDUCE_STAGE") && atoi(getenv("PTX_FRAME_REDUCE_STAGE")) != 0;
+	for (uint32_t i = 0; i < n_parts && e == hipSuccess; i++) {
+		if (parts[i]->scene->device == dev && !stage_all) e = add(parts[i]->accum);
+		else remote.push_back(parts[i]);
 	}
-	if (rc == PTX_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(PTX_ERR_DEVICE, "ptx_frame_reduce: synchronising the destination's stream failed");
+	const size_t group = std::max<size_t>(1, std::min<size_t>(remote.size(), (size_t(4) << 30) / bytes));   // at most 4 GB of staging films
+	void* staging = nullptr;
+	std::vector<hipStream_t> copy_streams;
+	std::vector<hipEvent_t> copied;
+	if (e == hipSuccess && !remote.empty()) e = hipMalloc(&staging, group * bytes);
+	for (size_t k = 0; k < group && e == hipSuccess && !remote.empty(); k++) {
+		hipStream_t st = nullptr;
+		hipEvent_t ev = nullptr;
+		e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+		if (e == hipSuccess) copy_streams.push_back(st), e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+		if (e == hipSuccess) copied.push_back(ev);
+	}
+	for (size_t first = 0; first < remote.size() && e == hipSuccess; first += group) {
+		const size_t count = std::min(group, remote.size() - first);
+		for (size_t k = 0; k < count && e == hipSuccess; k++) {
+			char* film = static_cast<char*>(staging) + k * bytes;
+			e = hipMemcpyPeerAsync(film, dev, remote[first + k]->accum, remote[first + k]->scene->device, bytes, copy_streams[k]);
+			if (e == hipSuccess) e = hipEventRecord(copied[k], copy_streams[k]);
+		}
+		for (size_t k = 0; k < count && e == hipSuccess; k++) {
+			e = hipStreamWaitEvent(stream, copied[k], 0);
+			if (e == hipSuccess) e = add(static_cast<char*>(staging) + k * bytes);
+		}
+		if (e == hipSuccess) e = hipStreamSynchronize(stream);   // the staging films are reused by the next group
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(stream);
+	for (hipStream_t st : copy_streams) (void)hipStreamSynchronize(st), (void)hipStreamDestroy(st);
+	for (hipEvent_t ev : copied) (void)hipEventDestroy(ev);
 	if (staging) (void)hipFree(staging);
-	return rc;
+	return e == hipSuccess ? PTX_OK : hip_fail(e, "ptx_frame_reduce");
 }
 
 extern "C" void ptx_frame_destroy(ptx_frame_t f) {

@@ -115,7 +115,11 @@ def test_cpp_facade_host_side(tmp_path):
 
 @pytest.mark.gpu
 def test_cpp_facade_on_gpu(tmp_path):
-    out = subprocess.check_output([_build_facade_check(tmp_path), "gpu"], text=True)
+    exe = _build_facade_check(tmp_path)
+    out = subprocess.check_output([exe, "gpu"], text=True)
+    assert "gpu checks passed" in out
+    # ptx_frame_reduce's path for films on other GPUs (staging films, one copy stream per part), forced on one GPU
+    out = subprocess.check_output([exe, "gpu"], text=True, env=dict(os.environ, PTX_FRAME_REDUCE_STAGE="1"))
     assert "gpu checks passed" in out
 
 

@@ -37,6 +37,9 @@ def delta_room():
 CONFIGS = {
     "1": ("cbox 256x256 16 spp depth 4", lambda: fixture("cbox"), 256, 16, 4),
     "2": ("refract_cow_cbox 1024x1024 256 spp depth 8", lambda: fixture("refract_cow_cbox"), 1024, 256, 8),
+    "2b": ("refract_cow_cbox 2048x2048 64 spp depth 8", lambda: fixture("refract_cow_cbox"), 2048, 64, 8),
+    "2c": ("refract_cow_cbox 4096x4096 16 spp depth 8", lambda: fixture("refract_cow_cbox"), 4096, 16, 8),
+    "2d": ("refract_cow_cbox 512x512 1024 spp depth 8", lambda: fixture("refract_cow_cbox"), 512, 1024, 8),
     "5": ("12^3 instanced cows 1024x1024 64 spp depth 8", lambda: scenes.instanced_cows(12), 1024, 64, 8),
     "d": ("delta-lit room 1024x1024 64 spp depth 4", delta_room, 1024, 64, 4),
 }

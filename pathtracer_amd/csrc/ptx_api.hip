@@ -568,7 +568,7 @@ struct PersistentBuffers {
 
 // Groups the batch by origin cell and direction octant (raysort.hip.h); *order receives the
 // device array of ray indices in that order.
-static int sort_rays(PtxScene* s, const PtxRay* d_rays, uint64_t n, const PersistentBuffers& pb, const uint32_t** order) {
+static int sort_rays(PtxScene* s, const PtxRay* d_rays, uint64_t n, const PersistentBuffers& pb, bool cost_classes, const uint32_t** order) {
 	uint32_t n_tiles, n_chunks, table_len;
 	sort_table_shape(n, n_tiles, n_chunks, table_len);
 	uint32_t* keys0 = pb.keys;
@@ -589,11 +589,12 @@ static int sort_rays(PtxScene* s, const PtxRay* d_rays, uint64_t n, const Persis
 	scale.x = ex > 0.0f ? cells / ex : 0.0f, scale.y = ey > 0.0f ? cells / ey : 0.0f, scale.z = ez > 0.0f ? cells / ez : 0.0f;
 	// Cost classes of the grouping key: chords below 7.5 % and 15 % of the root box's mean extent are queued last
 	// (16.7 M rays: 1 % faster, 4 M: 4 %).  Small batches keep one class: there the thinner classes cost more
-	// coherence than the shorter tail gains (1 M rays: 4 % slower with classes).
+	// coherence than the shorter tail gains (1 M rays: 4 % slower with classes), and so do occlusion queries,
+	// whose rays end at their first hit (16.7 M shadow rays: 3 % slower with classes).
 	static const float f1 = getenv("PTX_SORT_CLASS_T1") ? float(atof(getenv("PTX_SORT_CLASS_T1"))) : 0.075f;
 	static const float f2 = getenv("PTX_SORT_CLASS_T2") ? float(atof(getenv("PTX_SORT_CLASS_T2"))) : 0.15f;
 	const float3 hi = make_float3(root.bmax[0], root.bmax[1], root.bmax[2]);
-	const float mean_extent = n >= (uint64_t(1) << 21) ? (ex + ey + ez) / 3.0f : 0.0f;
+	const float mean_extent = cost_classes && n >= (uint64_t(1) << 21) ? (ex + ey + ez) / 3.0f : 0.0f;
 	const dim3 block(256), grid(n_tiles);
 	const size_t pad = size_t(table_len) - size_t(SORT_DIGITS) * n_tiles;
 	if (pad) PTX_HIP(hipMemsetAsync(table + size_t(SORT_DIGITS) * n_tiles, 0, pad * sizeof(uint32_t), s->stream));
@@ -637,7 +638,7 @@ static int launch_persistent(PtxScene* s, bool culled, bool sort, const Persiste
 	if (n >= (uint64_t(1) << 32)) return fail(PTX_ERR_INVALID, "ray count too large for one launch");
 	const uint32_t* order = nullptr;
 	if (wants_grouping(sort, n))
-		if (int rc = sort_rays(s, d_rays, n, pb, &order)) return rc;
+		if (int rc = sort_rays(s, d_rays, n, pb, !ANY, &order)) return rc;
 	unsigned long long* const next_ray = pb.counters;
 	PTX_HIP(hipMemsetAsync(next_ray, 0, (pb.slow_list2 ? 2 : 1) * COUNTER_BLOCK_BYTES, s->stream));
 	uint32_t* slow_list = pb.slow_list;

@@ -326,6 +326,19 @@ __device__ __forceinline__ Surface rebuild_surface(const SceneRec& sc, const Sha
 	return s;
 }
 
+#ifdef PTX_PROFILE_SHADE
+// Lane statistics of k_shade (a -DPTX_PROFILE_SHADE build): per site, the lanes that were active and the waves that came by.
+static __device__ unsigned long long g_shade_prof[32];
+#define SHADE_SITE(k)                                                                                  \
+	do {                                                                                               \
+		const unsigned long long m_ = __ballot(1);                                                     \
+		if ((threadIdx.x & 63u) == unsigned(__ffsll((long long)m_) - 1))                               \
+			atomicAdd(&g_shade_prof[2 * (k)], (unsigned long long)__popcll(m_)), atomicAdd(&g_shade_prof[2 * (k) + 1], 1ull); \
+	} while (0)
+#else
+#define SHADE_SITE(k) do { } while (0)
+#endif
+
 // The body of Pathtracer::trace for one active path, one recursion level per launch.
 // DELTA: the scene has point/spot/directional lights.  Their shadow rays are not walked here: the kernel leaves,
 // per light, the shadow ray and what the light adds when unoccluded; an occlusion pass over all of them follows
@@ -341,6 +354,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 	bool alive = false, wants_direct = false;
 	uint32_t path = 0;
 	if (i < *count) {
+		SHADE_SITE(0);
 		path = list[i];
 		const float4 st = rb.state[path];
 		V3f T = v3(st.x, st.y, st.z);
@@ -362,6 +376,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 
 		// ---- the direct ray traced last round: trace(rng, new_in_ray).first (pathtracer.cpp:71-76)
 		if (word & PATH_HAS_DIRECT) {
+			SHADE_SITE(1);
 			// the direct ray itself is read back only where its direction or origin matters
 			const float4 da = rb.hit_a[1][path];
 			const uint2 db = rb.hit_b[1][path];
@@ -400,6 +415,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 			// the scattered ray of the path's last vertex: trace() would return {emissive, {}} for it and
 			// sample_indirect_lighting uses `.second` only (pathtracer.cpp:118,163); it may not even have been traced
 		} else {
+			SHADE_SITE(2);
 			const float4 ma = rb.ray_a[0][path], mb = rb.ray_b[0][path];
 			const float4 ha = rb.hit_a[0][path];
 			const uint2 hb = rb.hit_b[0][path];
@@ -408,6 +424,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 				// miss: {env, {}} -- only a camera ray's (or a direct ray's) `.first` is ever used
 				if (camera && hb.x == 0xFFFFFFFFu && sh.n_env_lights) add_radiance(env_radiance(sh, ray_d));
 			} else {
+				SHADE_SITE(3);
 				const Ray3 r{ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
 				HitRec mh{};
 				mh.distance = ha.x, mh.t = ha.y, mh.u = ha.z, mh.v = ha.w, mh.prim = hb.x, mh.inst = hb.y;
@@ -419,6 +436,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 				// an indirect ray contributes `.second` only; every material but Emissive emits a zero Spectrum
 				if (camera && m.type == PTX_MAT_EMISSIVE) add_radiance(bsdf_emission(sh, m, s.u, s.v));
 				if (depth != 0 && m.type != PTX_MAT_EMISSIVE) {   // pathtracer.cpp:163
+					SHADE_SITE(4);
 					// sum_delta_lights (pathtracer.cpp:645-666): shadow rays and contributions for the occlusion pass
 					if (DELTA && !mat_is_specular(m.type)) {
 						lights_written = true;
@@ -450,9 +468,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 						// The ray brings back `first`, the emission of the first surface it meets; the path gains first * Wd.
 						// Where first is provably zero and Wd finite that is +-0, and L + (+-0) == L: the ray is left out.
 						wants_direct = true;
+						if (sh.direct_skip && finite3(Wd)) SHADE_SITE(5);
 						if (sh.direct_skip && finite3(Wd))
 							wants_direct = direct_ray_may_see_light(sc, sh, Ray3{s.position.x, s.position.y, s.position.z, in_world.x, in_world.y, in_world.z, RAY_MINIMUM_BOUND, INFINITY});
 						if (wants_direct) {
+							SHADE_SITE(6);
 							rb.wd[path] = make_float4(Wd.x, Wd.y, Wd.z, 0.0f);
 							rb.ray_a[1][path] = make_float4(s.position.x, s.position.y, s.position.z, in_world.x);
 							rb.ray_b[1][path] = make_float4(in_world.y, in_world.z, RAY_MINIMUM_BOUND, INFINITY);
@@ -774,6 +794,18 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 			std::fprintf(stderr, "[render rays] %llu paths: %llu main rays, %llu direct rays traced (%.2f rays per path)\n", (unsigned long long)chunk_paths, (unsigned long long)n_main_rays,
 			             (unsigned long long)n_direct_rays, double(n_main_rays + n_direct_rays) / double(chunk_paths ? chunk_paths : 1));
 	}
+#ifdef PTX_PROFILE_SHADE
+	{
+		unsigned long long h[32] = {}, zero[32] = {};
+		PTX_HIP(hipStreamSynchronize(s->stream));
+		PTX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shade_prof), sizeof(h)));
+		PTX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), zero, sizeof(zero)));
+		static const char* const site[] = {"listed path", "direct ray's result", "main ray's vertex", "surface rebuilt", "scatter (both samples)", "emitter pre-test", "direct ray written"};
+		for (int k = 0; k < 7; k++)
+			std::fprintf(stderr, "[shade lanes] %-24s %12llu wave visits, %5.1f lanes, %6.2f %% of listed paths\n", site[k], h[2 * k + 1], double(h[2 * k]) / double(h[2 * k + 1] ? h[2 * k + 1] : 1),
+			             100.0 * double(h[2 * k]) / double(h[0] ? h[0] : 1));
+	}
+#endif
 	if (host) {
 		PTX_HIP(hipMemcpyAsync(accum_rgb, d_accum, n_pixels * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
 		PTX_HIP(hipMemcpyAsync(samples, d_samples, n_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));

@@ -4,6 +4,7 @@ profiles/ for one round:  python tools/summarise_profiles.py r02
   rNN_bench_line.json          the line that command printed
   rNN_traffic.json             L2<->fabric bytes per launch of the culled closest-hit kernel, L2 hit rate
   rNN_pmc_closest.json         per-launch counter sums of that kernel + derived busy fractions
+  rNN_pmc_other_queries.json   the same for closest hit in the reference order (the API's default) and for occlusion queries
   rNN_kernel_stats_render.csv  per-kernel time of a config-2 render (refract_cow_cbox 1024x1024, 256 spp)
   rNN_pmc_scene.json           counter sums of the render's kernels (two-level extend, shade, raygen) over a 16 spp render
 Run here after the gpurun call has merged gpurun_out/ back."""
@@ -117,6 +118,27 @@ if "SQ_INSTS_VALU" in cnt and "GRBM_GUI_ACTIVE" in cnt:
                        "(cycles per XCD) measured in the same pass; valu_lane_throughput_frac = SQ_THREAD_CYCLES_VALU / (256 CUs x 64 lanes x cycles)",
                "counters": cnt, "derived": d}, open(os.path.join(P, f"{RND}_pmc_closest.json"), "w"), indent=1)
     print("closest:", json.dumps(d, indent=1))
+
+# ---- the other two ray queries of the bench: reference-order closest hit, culled occlusion
+others = {}
+for label, like in (("closest hit, reference order: k_mesh_persistent<0, false, false, false>", "k_mesh_persistent<0, false, false, false>"),
+                    ("occlusion, culled order: k_mesh_persistent<1, true, false, false>", "k_mesh_persistent<1, true, false, false>")):
+    c2 = {}
+    for d in ("o_fetch", "o_l2", "o_sq", "o_mem"):
+        c2.update(sums(d, like))
+    if "SQ_INSTS_VALU" in c2 and "GRBM_GUI_ACTIVE" in c2:
+        d2 = derived(c2, N_RAYS)
+        d2["l1_access_rate_frac"] = c2["TCP_TOTAL_CACHE_ACCESSES_sum"] / (d2["cycles_per_xcd"] * CUS)
+        d2["l1_accesses_per_ray"] = c2["TCP_TOTAL_CACHE_ACCESSES_sum"] / N_RAYS
+        d2["fabric_read_bytes_per_launch"] = c2.get("FETCH_SIZE", 0.0) * 1024.0
+        others[label] = {"counters": c2, "derived": d2}
+if others:
+    json.dump({"round": RND, "workload": "16777216 rays vs the 1M-triangle soup (closest-hit rays / shadow rays of the bench)",
+               "command": "rocprofv3 --pmc <counters> -- python3 tools/prof_closest.py 16777216 2 ra   (one pass per counter group: tools/profile_gpu.sh)",
+               "note": "per-launch sums; derived fractions as in the culled closest-hit summary; l1_access_rate_frac = TCP_TOTAL_CACHE_ACCESSES_sum / (256 CUs x cycles)",
+               "kernels": others}, open(os.path.join(P, f"{RND}_pmc_other_queries.json"), "w"), indent=1)
+    for k, e in others.items():
+        print(k[:40], {a: round(b, 3) for a, b in e["derived"].items()})
 
 # ---- the bench line's roofline block again, from the summaries just written (the run itself used the summaries
 # committed before it: same formulas, this run's counters), so that the line and the files beside it agree exactly

@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 #endif
 		if (on_node != 0ull) {
 			if (!(ref & REF_LEAF)) {
-				node_step<MODE, ANY, true, false, ZERO>(nodes, r, inv, st, 0, sp, ref, cur.hit, cur.distance, nullptr);
+				node_step<MODE, ANY, true, false, ZERO, true>(nodes, r, inv, st, 0, sp, ref, cur.hit, cur.distance, nullptr);
 				tri_k = 0;
 			}
 		}

@@ -308,12 +308,15 @@ __device__ __forceinline__ void pop_ref(const Ray3& r, StackType& st, const int 
 // first three 16-byte pieces (left box, right box), kids its two child references.
 // DEFER_POP: when neither child is taken, leave REF_NONE in `ref` instead of popping, so that a caller
 // with other reasons to pop (a leaf it parks) runs one pop loop for all of them.
-template<int MODE, bool ANY, bool FAST, bool DEFER_POP = false, bool ZERO = false, typename StackType>
+// APPROX: decide with slab_test_approx (exact test where it cannot tell).  The culled order always does (it also
+// wants the entry distances); the reference order needs the decisions only, and the replenishing kernel asks for the
+// cheaper form while the one-ray-per-lane kernels keep the plain exact test.
+template<int MODE, bool ANY, bool FAST, bool DEFER_POP = false, bool ZERO = false, bool APPROX = (MODE == MODE_CULLED), typename StackType>
 __device__ __forceinline__ void node_decide(const float4 n0, const float4 n1, const float4 n2, const uint2 kids, const Ray3& r, const RayInv& inv, StackType& st,
                                             const int base, int& sp, uint32_t& ref, bool run_hit, float run_dist) {
 	float tl, tr;
 	bool hl, hr;
-	if (FAST && MODE == MODE_CULLED) {
+	if (FAST && APPROX) {
 		bool al, ar;
 		hl = slab_test_approx<ZERO>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, inv, tl, al);
 		hr = slab_test_approx<ZERO>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, inv, tr, ar);
@@ -402,7 +405,7 @@ __device__ __forceinline__ void node4_decide(const Node4* __restrict__ node, con
 	ref = n > 0 ? val[0] : REF_NONE;
 }
 
-template<int MODE, bool ANY, bool FAST, bool STATS, bool ZERO = false, typename StackType>
+template<int MODE, bool ANY, bool FAST, bool STATS, bool ZERO = false, bool APPROX = (MODE == MODE_CULLED), typename StackType>
 __device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const Ray3& r, const RayInv& inv, StackType& st, const int base, int& sp,
                                           uint32_t& ref, bool run_hit, float run_dist, TraverseStats* stats) {
 	const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
@@ -410,7 +413,7 @@ __device__ __forceinline__ void node_step(const Node2* __restrict__ nodes, const
 	const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
 	if (STATS) stats->nodes++;
 	if (STATS) stats->max_sp = max(stats->max_sp, uint32_t(sp - base));
-	node_decide<MODE, ANY, FAST, false, ZERO>(n0, n1, n2, kids, r, inv, st, base, sp, ref, run_hit, run_dist);
+	node_decide<MODE, ANY, FAST, false, ZERO, APPROX>(n0, n1, n2, kids, r, inv, st, base, sp, ref, run_hit, run_dist);
 }
 
 // A whole traversal: walk interior nodes until every lane of the wave holds a leaf (or is

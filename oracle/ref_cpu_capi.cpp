@@ -182,6 +182,12 @@ void orc_scene_mesh_get_stats(void* h, uint32_t mesh, uint64_t* out) {
 	out[0] = b.clamped, out[1] = b.predicate_disagreements, out[2] = b.dropped;
 }
 
+// The same counters for the instance-level tree (all zero for a List<Instance> scene).
+void orc_scene_top_get_stats(void* h, uint64_t* out) {
+	const auto& b = static_cast<OScene*>(h)->scene.top;
+	out[0] = b.clamped, out[1] = b.predicate_disagreements, out[2] = b.dropped;
+}
+
 uint32_t orc_scene_top_num_nodes(void* h) { return uint32_t(static_cast<OScene*>(h)->scene.top.nodes.size()); }
 
 void orc_scene_top_get_nodes(void* h, PtxBvhNode* out) {

@@ -65,6 +65,7 @@ class Oracle:
         L.orc_scene_mesh_get_nodes.argtypes = [vp, C.c_uint32, nodep]
         L.orc_scene_mesh_get_order.argtypes = [vp, C.c_uint32, abi.u32p]
         L.orc_scene_mesh_get_stats.argtypes = [vp, C.c_uint32, u64p]
+        L.orc_scene_top_get_stats.argtypes = [vp, u64p]
         L.orc_scene_top_num_nodes.restype = C.c_uint32
         L.orc_scene_top_num_nodes.argtypes = [vp]
         L.orc_scene_top_get_nodes.argtypes = [vp, nodep]
@@ -237,6 +238,11 @@ class OracleScene:
     def mesh_stats(self, mesh=0):
         out = np.zeros(3, dtype=np.uint64)
         self.o.L.orc_scene_mesh_get_stats(self.h, mesh, _ptr(out, u64p))
+        return out
+
+    def top_stats(self):
+        out = np.zeros(3, dtype=np.uint64)
+        self.o.L.orc_scene_top_get_stats(self.h, _ptr(out, u64p))
         return out
 
     def top_nodes(self):

@@ -29,7 +29,14 @@ constexpr int STUCK_MAX_LANES = 16;   // ... or this many lanes cannot go on wal
 #ifndef PTX_LDS_SLOTS
 #define PTX_LDS_SLOTS 12
 #endif
+#ifndef PTX_TOP_NODES
+#define PTX_TOP_NODES 0
+#endif
 constexpr int PERSISTENT_LDS_SLOTS = PTX_LDS_SLOTS;   // stack entries per lane kept in LDS (8 B each)
+// The culled-order walk keeps the first TOP_NODES records of the node array -- the top of the tree, numbered
+// breadth-first by the host's flattener -- in LDS: every ray passes through them, and a lane's 64-byte record comes
+// out of LDS in four bank-parallel reads where the vector L1 spends four of its one-per-clock line look-ups.
+constexpr int TOP_NODES = PTX_TOP_NODES;
 constexpr unsigned RAY_PARTS = 8;           // parts of the ray order with their own claim counter (one per XCD)
 constexpr unsigned PART_COUNTER0 = 32, PART_COUNTER_STRIDE = 8;   // in 8-byte words of the counter block: bytes 256, 320, ... (a 64-byte line each)
 constexpr size_t COUNTER_BLOCK_BYTES = 1024;
@@ -60,6 +67,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 
 	__shared__ uint32_t lds_ref[PERSISTENT_LDS_SLOTS * 256];
 	__shared__ float lds_tnear[PERSISTENT_LDS_SLOTS * 256];
+	constexpr int TOP = (MODE == MODE_CULLED && !WIDE && !ZERO) ? TOP_NODES : 0;
+	__shared__ float4 lds_top[TOP > 0 ? TOP * 4 : 1];
+	if (TOP > 0) {
+		// the node array is padded by TOP_NODES records on the host, so this read stays inside it for any tree
+		for (int i = threadIdx.x; i < TOP * 4; i += 256) lds_top[i] = reinterpret_cast<const float4*>(nodes)[i];
+		__syncthreads();
+	}
 	Stack spill;
 	LdsStack<PERSISTENT_LDS_SLOTS, 256> st{lds_ref + threadIdx.x, lds_tnear + threadIdx.x, &spill};
 	// Parking leaves reorders triangle tests: fine for the culled mode (its tie rule is order free),
@@ -184,9 +198,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 						if (WIDE) {
 							node4_decide<ANY>(nodes4 + (ref & REF_INDEX_MASK), r, inv, st, sp, ref, cur.hit, cur.distance);
 						} else {
-							const float4* p = reinterpret_cast<const float4*>(nodes + (ref & REF_INDEX_MASK));
-							const float4 n0 = p[0], n1 = p[1], n2 = p[2];
-							const uint2 kids = *reinterpret_cast<const uint2*>(p + 3);
+							const uint32_t index = ref & REF_INDEX_MASK;
+							float4 n0, n1, n2;
+							uint2 kids;
+							if (TOP > 0 && index < uint32_t(TOP)) {
+								// address-space-typed reads (ds_read_b128); through a generic pointer they would be flat loads
+								typedef float V4 __attribute__((ext_vector_type(4)));
+								typedef __attribute__((address_space(3))) V4 LdsV4;
+								const LdsV4* q = (const LdsV4*)lds_top + index * 4u;
+								const V4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+								n0 = make_float4(q0.x, q0.y, q0.z, q0.w), n1 = make_float4(q1.x, q1.y, q1.z, q1.w), n2 = make_float4(q2.x, q2.y, q2.z, q2.w);
+								kids = make_uint2(__float_as_uint(q3.x), __float_as_uint(q3.y));
+							} else {
+								const float4* p = reinterpret_cast<const float4*>(nodes + index);
+								n0 = p[0], n1 = p[1], n2 = p[2];
+								kids = *reinterpret_cast<const uint2*>(p + 3);
+							}
 							node_decide<MODE, ANY, true, true, ZERO>(n0, n1, n2, kids, r, inv, st, 0, sp, ref, cur.hit, cur.distance);
 						}
 					}

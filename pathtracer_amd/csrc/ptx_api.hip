@@ -193,12 +193,24 @@ static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_pr
 		return PTX_OK;
 	}
 	std::vector<uint32_t> interior_of(n_nodes, 0xFFFFFFFFu);
-	std::vector<uint32_t> stack{0u};
 	uint32_t count = 0;
-	while (!stack.empty()) {  // number interior nodes depth-first, left first
+	if (TOP_NODES > 0) {
+		// The first TOP_NODES interior nodes breadth-first: the top of the tree gets the lowest indices, which is
+		// the part k_mesh_persistent keeps in LDS (persistent.hip.h).
+		std::vector<uint32_t> queue{0u};
+		for (size_t head = 0; head < queue.size() && count < uint32_t(TOP_NODES); head++) {
+			const uint32_t i = queue[head];
+			interior_of[i] = count++;
+			const PtxBvhNode& n = nodes[i];
+			if (nodes[n.l].l != nodes[n.l].r) queue.push_back(n.l);
+			if (nodes[n.r].l != nodes[n.r].r) queue.push_back(n.r);
+		}
+	}
+	std::vector<uint32_t> stack{0u};
+	while (!stack.empty()) {  // number the (other) interior nodes depth-first, left first
 		uint32_t i = stack.back();
 		stack.pop_back();
-		interior_of[i] = count++;
+		if (interior_of[i] == 0xFFFFFFFFu) interior_of[i] = count++;
 		const PtxBvhNode& n = nodes[i];
 		if (nodes[n.r].l != nodes[n.r].r) stack.push_back(n.r);
 		if (nodes[n.l].l != nodes[n.l].r) stack.push_back(n.l);
@@ -438,13 +450,16 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 
 static int finish_geometry(PtxScene* s, SceneBuild& sb) {
 	BuildLaps laps;
+	s->bytes_nodes = sb.nodes.size() * sizeof(Node2);
+	// k_mesh_persistent copies the first TOP_NODES records of a mesh's node array into LDS whatever the tree's size:
+	// zero records behind the last tree keep that read inside the allocation.
+	if (TOP_NODES > 0) sb.nodes.resize(sb.nodes.size() + size_t(TOP_NODES), Node2{});
 	if (int rc = upload(s, sb.nodes, s->rec.nodes)) return rc;
 	if (int rc = upload(s, sb.nodes4, s->rec.nodes4)) return rc;
 	if (int rc = upload(s, sb.tris, s->rec.tris)) return rc;
 	if (int rc = upload(s, sb.attrs, s->rec.attrs)) return rc;
 	if (int rc = upload(s, sb.meshes, s->rec.meshes)) return rc;
 	s->shade.attrs = s->rec.attrs;
-	s->bytes_nodes = sb.nodes.size() * sizeof(Node2);
 	s->bytes_tris = sb.tris.size() * sizeof(TriGeom);
 	laps.lap("upload");
 	return PTX_OK;

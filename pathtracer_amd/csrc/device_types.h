@@ -24,12 +24,30 @@ inline constexpr uint32_t make_leaf_ref(uint32_t start, uint32_t count) { return
 // Interior node of a binary tree: the boxes of both children and where they lead.
 // PT::BVH keeps one box per node (bvh.h:15-23) and tests it on entry (bvh.cpp:278-286);
 // holding the two child boxes in the parent is the same set of tests, one level earlier.
+// The twelve box coordinates are ordered for the two-wide vector ALU operations of the slab test: every 8-byte
+// pair below meets one pair of ray registers ((ox, oy) or (oz, oz)) in a single packed subtract and multiply, with
+// no register moves between the load and the arithmetic.
 struct alignas(64) Node2 {
-	float lmin[3], lmax[3];
-	float rmin[3], rmax[3];
+	float lxy[4];   // left child:  min.x, min.y, max.x, max.y
+	float z[4];     // left min.z, left max.z, right min.z, right max.z
+	float rxy[4];   // right child: min.x, min.y, max.x, max.y
 	uint32_t lref, rref;
 	uint32_t pad[2];
+	// side 0: left child, 1: right child
+	void set_box(int side, const float* bmin, const float* bmax) {
+		float* xy = side ? rxy : lxy;
+		xy[0] = bmin[0], xy[1] = bmin[1], xy[2] = bmax[0], xy[3] = bmax[1];
+		z[2 * side] = bmin[2], z[2 * side + 1] = bmax[2];
+	}
+	void get_box(int side, float* bmin, float* bmax) const {
+		const float* xy = side ? rxy : lxy;
+		bmin[0] = xy[0], bmin[1] = xy[1], bmax[0] = xy[2], bmax[1] = xy[3];
+		bmin[2] = z[2 * side], bmax[2] = z[2 * side + 1];
+	}
 };
+// The children's boxes from a node's first three 16-byte pieces, as (min.x, min.y, min.z, max.x, max.y, max.z).
+#define PTX_NODE_LEFT_BOX(n0, n1, n2) (n0).x, (n0).y, (n1).x, (n0).z, (n0).w, (n1).y
+#define PTX_NODE_RIGHT_BOX(n0, n1, n2) (n2).x, (n2).y, (n1).z, (n2).z, (n2).w, (n1).w
 static_assert(sizeof(Node2) == 64, "one cache line");
 
 // Interior node of the four-wide form of the same tree: a binary node with its interior children replaced by

@@ -30,7 +30,10 @@ constexpr int STUCK_MAX_LANES = 16;   // ... or this many lanes cannot go on wal
 #define PTX_LDS_SLOTS 12
 #endif
 #ifndef PTX_TOP_NODES
-#define PTX_TOP_NODES 0
+#define PTX_TOP_NODES 128
+#endif
+#ifndef PTX_LDS_SLOTS_TOP
+#define PTX_LDS_SLOTS_TOP 9   // stack entries in LDS for the instances that also keep the top of the tree there: 18 + 8 KB, six blocks per CU
 #endif
 constexpr int PERSISTENT_LDS_SLOTS = PTX_LDS_SLOTS;   // stack entries per lane kept in LDS (8 B each)
 // The culled-order walk keeps the first TOP_NODES records of the node array -- the top of the tree, numbered
@@ -65,9 +68,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 	const unsigned lane = threadIdx.x & 63u;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-	__shared__ uint32_t lds_ref[PERSISTENT_LDS_SLOTS * 256];
-	__shared__ float lds_tnear[PERSISTENT_LDS_SLOTS * 256];
 	constexpr int TOP = (MODE == MODE_CULLED && !WIDE && !ZERO) ? TOP_NODES : 0;
+	constexpr int LDS_SLOTS = TOP > 0 ? PTX_LDS_SLOTS_TOP : PERSISTENT_LDS_SLOTS;
+	__shared__ uint32_t lds_ref[LDS_SLOTS * 256];
+	__shared__ float lds_tnear[LDS_SLOTS * 256];
 	__shared__ float4 lds_top[TOP > 0 ? TOP * 4 : 1];
 	if (TOP > 0) {
 		// the node array is padded by TOP_NODES records on the host, so this read stays inside it for any tree
@@ -75,7 +79,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 		__syncthreads();
 	}
 	Stack spill;
-	LdsStack<PERSISTENT_LDS_SLOTS, 256> st{lds_ref + threadIdx.x, lds_tnear + threadIdx.x, &spill};
+	LdsStack<LDS_SLOTS, 256> st{lds_ref + threadIdx.x, lds_tnear + threadIdx.x, &spill};
 	// Parking leaves reorders triangle tests: fine for the culled mode (its tie rule is order free),
 	// not for the reference order.
 	constexpr bool POSTPONE = MODE == MODE_CULLED;
@@ -201,19 +205,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ?
 							const uint32_t index = ref & REF_INDEX_MASK;
 							float4 n0, n1, n2;
 							uint2 kids;
-							if (TOP > 0 && index < uint32_t(TOP)) {
-								// address-space-typed reads (ds_read_b128); through a generic pointer they would be flat loads
-								typedef float V4 __attribute__((ext_vector_type(4)));
-								typedef __attribute__((address_space(3))) V4 LdsV4;
-								const LdsV4* q = (const LdsV4*)lds_top + index * 4u;
-								const V4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-								n0 = make_float4(q0.x, q0.y, q0.z, q0.w), n1 = make_float4(q1.x, q1.y, q1.z, q1.w), n2 = make_float4(q2.x, q2.y, q2.z, q2.w);
-								kids = make_uint2(__float_as_uint(q3.x), __float_as_uint(q3.y));
-							} else {
-								const float4* p = reinterpret_cast<const float4*>(nodes + index);
-								n0 = p[0], n1 = p[1], n2 = p[2];
-								kids = *reinterpret_cast<const uint2*>(p + 3);
-							}
+							if (TOP > 0 && index < uint32_t(TOP)) fetch_node_lds(lds_top, index, n0, n1, n2, kids);
+							else fetch_node(nodes + index, n0, n1, n2, kids);
 							node_decide<MODE, ANY, true, true, ZERO>(n0, n1, n2, kids, r, inv, st, 0, sp, ref, cur.hit, cur.distance);
 						}
 					}

@@ -221,15 +221,13 @@ static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_pr
 		if (interior_of[i] == 0xFFFFFFFFu) continue;
 		const PtxBvhNode &n = nodes[i], &l = nodes[n.l], &r = nodes[n.r];
 		Node2& d = out.nodes[interior_of[i]];
-		for (int k = 0; k < 3; k++) d.lmin[k] = l.bmin[k], d.lmax[k] = l.bmax[k], d.rmin[k] = r.bmin[k], d.rmax[k] = r.bmax[k];
 		// An empty leaf (the reference's "no split separates the primitives" case, bvh.cpp:183-221)
 		// carries an inverted FLT_MAX box; whether a ray "hits" it changes nothing, so store zeros.
-		if (l.l == l.r && l.size == 0)
-			for (int k = 0; k < 3; k++) d.lmin[k] = d.lmax[k] = 0.0f;
-		if (r.l == r.r && r.size == 0)
-			for (int k = 0; k < 3; k++) d.rmin[k] = d.rmax[k] = 0.0f;
-		for (int k = 0; k < 3; k++)
-			out.tame = out.tame && tame_coord_host(d.lmin[k]) && tame_coord_host(d.lmax[k]) && tame_coord_host(d.rmin[k]) && tame_coord_host(d.rmax[k]);
+		const float zeros[3] = {0.0f, 0.0f, 0.0f};
+		const bool l_empty = l.l == l.r && l.size == 0, r_empty = r.l == r.r && r.size == 0;
+		d.set_box(0, l_empty ? zeros : l.bmin, l_empty ? zeros : l.bmax);
+		d.set_box(1, r_empty ? zeros : r.bmin, r_empty ? zeros : r.bmax);
+		for (int k = 0; k < 4; k++) out.tame = out.tame && tame_coord_host(d.lxy[k]) && tame_coord_host(d.z[k]) && tame_coord_host(d.rxy[k]);
 		if (l.l == l.r) {
 			if (!leaf_ref(n.l, d.lref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
 		} else d.lref = interior_of[n.l] | (sticks_out[n.l] ? REF_NOCULL : 0u);
@@ -259,7 +257,7 @@ static void widen_tree(const FlatTree& in, std::vector<Node4>& out, uint32_t& ro
 	};
 	auto kids_of = [&](uint32_t idx, Kid k[2]) {
 		const Node2& n = in.nodes[idx];
-		for (int a = 0; a < 3; a++) k[0].lo[a] = n.lmin[a], k[0].hi[a] = n.lmax[a], k[1].lo[a] = n.rmin[a], k[1].hi[a] = n.rmax[a];
+		n.get_box(0, k[0].lo, k[0].hi), n.get_box(1, k[1].lo, k[1].hi);
 		k[0].ref = n.lref, k[1].ref = n.rref;
 	};
 	auto inside = [](const Kid& g, const Kid& c) {
@@ -295,10 +293,7 @@ static void widen_tree(const FlatTree& in, std::vector<Node4>& out, uint32_t& ro
 		uint32_t wref[4] = {REF_NONE4, REF_NONE4, REF_NONE4, REF_NONE4};
 		for (int c = 0; c < n4; c++) {
 			Node2& hf = w.half[c >> 1];
-			for (int a = 0; a < 3; a++) {
-				if (c & 1) hf.rmin[a] = four[c].lo[a], hf.rmax[a] = four[c].hi[a];
-				else hf.lmin[a] = four[c].lo[a], hf.lmax[a] = four[c].hi[a];
-			}
+			hf.set_box(c & 1, four[c].lo, four[c].hi);
 			if (four[c].ref & REF_LEAF) {
 				wref[c] = four[c].ref;
 			} else {

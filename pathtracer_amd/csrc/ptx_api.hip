@@ -464,7 +464,7 @@ static int finish_geometry(PtxScene* s, SceneBuild& sb) {
 // Callers that may not allocate (HIP graph capture, tight serving loops) get the replenishing kernel's
 // working buffers from this file-scope device array instead of hipMalloc: every GPU the library runs on
 // holds one copy until the process ends.  Layout for up to NOALLOC_MAX_RAYS rays:
-//   [counters 1 KB][slow list n][keys 2n][indices 2n][table + chunk totals]     (n in uint32)
+//   [counters 1 KB][slow list n][keys n, final order n][(key, ray index) pairs 2n][table + chunk totals]     (n in uint32)
 constexpr uint64_t NOALLOC_MAX_RAYS = PTX_NOALLOC_MAX_RAYS;
 constexpr size_t noalloc_table_words() {
 	return size_t((SORT_DIGITS * uint32_t((NOALLOC_MAX_RAYS + SORT_TILE - 1) / SORT_TILE) + SCAN_CHUNK - 1) / SCAN_CHUNK) * (SCAN_CHUNK + 1);
@@ -581,10 +581,9 @@ struct PersistentBuffers {
 static int sort_rays(PtxScene* s, const PtxRay* d_rays, uint64_t n, const PersistentBuffers& pb, bool cost_classes, const uint32_t** order) {
 	uint32_t n_tiles, n_chunks, table_len;
 	sort_table_shape(n, n_tiles, n_chunks, table_len);
-	uint32_t* keys0 = pb.keys;
-	uint32_t* keys1 = keys0 + n;
-	uint32_t* idx1 = pb.idx;
-	uint32_t* ord = idx1 + n;
+	uint32_t* keys0 = pb.keys;                          // pb.keys: 2n words -- the keys, then the final order
+	uint32_t* ord = keys0 + n;
+	uint2* pairs = reinterpret_cast<uint2*>(pb.idx);    // pb.idx: 2n words, 8-byte aligned -- the first pass's (key, ray index) pairs
 	uint32_t* table = pb.table;
 	uint32_t* totals = table + table_len;
 	auto scan = [&]() {
@@ -610,10 +609,10 @@ static int sort_rays(PtxScene* s, const PtxRay* d_rays, uint64_t n, const Persis
 	if (pad) PTX_HIP(hipMemsetAsync(table + size_t(SORT_DIGITS) * n_tiles, 0, pad * sizeof(uint32_t), s->stream));
 	hipLaunchKernelGGL(k_sort_count_rays, grid, block, 0, s->stream, d_rays, n, lo, scale, hi, f1 * mean_extent, f2 * mean_extent, keys0, table, n_tiles);
 	scan();
-	hipLaunchKernelGGL(k_sort_scatter<true>, grid, block, 0, s->stream, keys0, static_cast<const uint32_t*>(nullptr), n, table, n_tiles, keys1, idx1);
-	hipLaunchKernelGGL(k_sort_count_keys, grid, block, 0, s->stream, keys1, n, table, n_tiles);
+	hipLaunchKernelGGL(k_sort_scatter<true>, grid, block, 0, s->stream, keys0, static_cast<const uint2*>(nullptr), n, table, n_tiles, pairs, static_cast<uint32_t*>(nullptr));
+	hipLaunchKernelGGL(k_sort_count_keys, grid, block, 0, s->stream, pairs, n, table, n_tiles);
 	scan();
-	hipLaunchKernelGGL(k_sort_scatter<false>, grid, block, 0, s->stream, keys1, idx1, n, table, n_tiles, static_cast<uint32_t*>(nullptr), ord);
+	hipLaunchKernelGGL(k_sort_scatter<false>, grid, block, 0, s->stream, static_cast<const uint32_t*>(nullptr), pairs, n, table, n_tiles, static_cast<uint2*>(nullptr), ord);
 	*order = ord;
 	return PTX_OK;
 }

@@ -97,13 +97,13 @@ __global__ void __launch_bounds__(256) k_sort_count_rays(const PtxRay* __restric
 	for (uint32_t d = threadIdx.x; d < SORT_DIGITS; d += blockDim.x) table[size_t(d) * n_tiles + blockIdx.x] = hist[d];
 }
 
-// Pass 1 count: high-digit histogram of a tile of the first pass's output.
-__global__ void __launch_bounds__(256) k_sort_count_keys(const uint32_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ table, uint32_t n_tiles) {
+// Pass 1 count: high-digit histogram of a tile of the first pass's output ((key, ray index) pairs).
+__global__ void __launch_bounds__(256) k_sort_count_keys(const uint2* __restrict__ pairs, uint64_t n, uint32_t* __restrict__ table, uint32_t n_tiles) {
 	__shared__ uint32_t hist[SORT_DIGITS];
 	for (uint32_t d = threadIdx.x; d < SORT_DIGITS; d += blockDim.x) hist[d] = 0;
 	__syncthreads();
 	const uint64_t begin = uint64_t(blockIdx.x) * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
-	for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&hist[keys[i] >> SORT_DIGIT_BITS], 1u);
+	for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&hist[pairs[i].x >> SORT_DIGIT_BITS], 1u);
 	__syncthreads();
 	for (uint32_t d = threadIdx.x; d < SORT_DIGITS; d += blockDim.x) table[size_t(d) * n_tiles + blockIdx.x] = hist[d];
 }
@@ -165,22 +165,27 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ table, 
 	p[0] = a, p[1] = b;
 }
 
-// Scatter of one pass.  FIRST: values are the rays' own indices and keys travel along; else values
-// are the first pass's indices and only they are written (the final order).
+// Scatter of one pass.  FIRST: by the key's low digit; the key and the ray's own index travel together as one
+// 8-byte pair (one scattered store per ray, and the ~16 rays a tile sends to a bin fill a 128-byte run).  Else: by the
+// high digit of the first pass's pairs, and only the ray index is written (the final order).
 template<bool FIRST>
-__global__ void __launch_bounds__(256) k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ values_in, uint64_t n,
-                                                      const uint32_t* __restrict__ table, uint32_t n_tiles, uint32_t* __restrict__ keys_out,
-                                                      uint32_t* __restrict__ values_out) {
+__global__ void __launch_bounds__(256) k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint2* __restrict__ pairs_in, uint64_t n,
+                                                      const uint32_t* __restrict__ table, uint32_t n_tiles, uint2* __restrict__ pairs_out,
+                                                      uint32_t* __restrict__ order_out) {
 	__shared__ uint32_t offset[SORT_DIGITS];
 	for (uint32_t d = threadIdx.x; d < SORT_DIGITS; d += blockDim.x) offset[d] = table[size_t(d) * n_tiles + blockIdx.x];
 	__syncthreads();
 	const uint64_t begin = uint64_t(blockIdx.x) * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
 	for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
-		const uint32_t k = keys_in[i];
-		const uint32_t d = FIRST ? (k & (SORT_DIGITS - 1u)) : (k >> SORT_DIGIT_BITS);
-		const uint32_t pos = atomicAdd(&offset[d], 1u);
-		if (FIRST) keys_out[pos] = k, values_out[pos] = uint32_t(i);
-		else values_out[pos] = values_in[i];
+		if (FIRST) {
+			const uint32_t k = keys_in[i];
+			const uint32_t pos = atomicAdd(&offset[k & (SORT_DIGITS - 1u)], 1u);
+			pairs_out[pos] = make_uint2(k, uint32_t(i));
+		} else {
+			const uint2 p = pairs_in[i];
+			const uint32_t pos = atomicAdd(&offset[p.x >> SORT_DIGIT_BITS], 1u);
+			order_out[pos] = p.y;
+		}
 	}
 }
 

@@ -176,15 +176,29 @@ __global__ void __launch_bounds__(256) k_sort_scatter(const uint32_t* __restrict
 	for (uint32_t d = threadIdx.x; d < SORT_DIGITS; d += blockDim.x) offset[d] = table[size_t(d) * n_tiles + blockIdx.x];
 	__syncthreads();
 	const uint64_t begin = uint64_t(blockIdx.x) * SORT_TILE, end = begin + SORT_TILE < n ? begin + SORT_TILE : n;
-	for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
-		if (FIRST) {
-			const uint32_t k = keys_in[i];
-			const uint32_t pos = atomicAdd(&offset[k & (SORT_DIGITS - 1u)], 1u);
-			pairs_out[pos] = make_uint2(k, uint32_t(i));
-		} else {
-			const uint2 p = pairs_in[i];
-			const uint32_t pos = atomicAdd(&offset[p.x >> SORT_DIGIT_BITS], 1u);
-			order_out[pos] = p.y;
+	// Four rays per thread and step: the four loads are in flight together, then the four LDS atomics, then the
+	// four stores (a tile is walked by one block of four waves, so the latencies of a one-ray chain would show).
+	constexpr uint32_t UNROLL = 4;
+	for (uint64_t base = begin + threadIdx.x; base < end; base += uint64_t(UNROLL) * blockDim.x) {
+		uint2 item[UNROLL];
+		uint32_t pos[UNROLL];
+#pragma unroll
+		for (uint32_t u = 0; u < UNROLL; u++) {
+			const uint64_t i = base + uint64_t(u) * blockDim.x;
+			if (i < end) item[u] = FIRST ? make_uint2(keys_in[i], uint32_t(i)) : pairs_in[i];
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < UNROLL; u++) {
+			const uint64_t i = base + uint64_t(u) * blockDim.x;
+			if (i < end) pos[u] = atomicAdd(&offset[FIRST ? (item[u].x & (SORT_DIGITS - 1u)) : (item[u].x >> SORT_DIGIT_BITS)], 1u);
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < UNROLL; u++) {
+			const uint64_t i = base + uint64_t(u) * blockDim.x;
+			if (i < end) {
+				if (FIRST) pairs_out[pos[u]] = item[u];
+				else order_out[pos[u]] = item[u].y;
+			}
 		}
 	}
 }

@@ -244,6 +244,10 @@ int ptx_scene_set_stream(ptx_scene_t scene, void* hip_stream);
 uint32_t ptx_scene_mesh_num_nodes(ptx_scene_t scene, uint32_t mesh);
 int ptx_scene_mesh_get_nodes(ptx_scene_t scene, uint32_t mesh, PtxBvhNode* out);
 int ptx_scene_mesh_get_order(ptx_scene_t scene, uint32_t mesh, uint32_t* out);
+/* 1 when mesh `mesh`'s tree was built by the GPU builder (meshes of 131,072 triangles and more, unless PTX_GPU_BUILD
+ * says otherwise), 0 when by the host builder -- also after the GPU builder failed for want of device memory and the
+ * library fell back to the host builder, which gives the same tree byte for byte. */
+int ptx_scene_mesh_built_on_device(ptx_scene_t scene, uint32_t mesh);
 /* BVH-ordered instance array of the top level: input index of the i-th instance. */
 int ptx_scene_get_instance_order(ptx_scene_t scene, uint32_t* out);
 
@@ -335,9 +339,40 @@ int ptx_frame_clear(ptx_frame_t frame);
  * (pathtracer.cpp:566-584, 407-427).  With several GPUs every GPU accumulates the tiles it was dealt in a film of its
  * own (ptx_frame_create on that GPU's scene); ptx_frame_reduce then adds every part into `dst` (dst += sum of parts,
  * parts unchanged): integer sums of 40.24 fixed-point values and of the sample counts, so the frame is the one a single
- * accumulator would hold, whatever the order (pathtracer.h:80-83).  Parts on another GPU than dst's are brought over
- * with one peer copy each (xGMI where the GPUs are linked).  No work may be in flight on the parts while it runs. */
+ * accumulator would hold, whatever the order (pathtracer.h:80-83).  Parts on dst's own GPU and on GPUs it can address
+ * as peers (xGMI; peer access is enabled on first use) are read where they lie by one kernel per eight parts; parts it
+ * cannot address are copied into staging films on dst's GPU first.  Staging memory, copy streams and events belong to
+ * `dst` and are kept until it is destroyed: calls after the first allocate nothing.  No work may be in flight on the
+ * parts while it runs. */
 int ptx_frame_reduce(ptx_frame_t dst, const ptx_frame_t* parts, uint32_t n_parts);
+/* What the last ptx_frame_reduce into `dst` did (no counterpart in the reference: its accumulator never leaves one
+ * address space). */
+typedef struct PtxFrameReduceInfo {
+	uint32_t parts_local;        /* parts on dst's GPU, added where they lie */
+	uint32_t parts_peer_direct;  /* parts on another GPU, read over the link by the adding kernel (peer access) */
+	uint32_t parts_staged;       /* parts copied into a staging film first (no peer access, or PTX_FRAME_REDUCE_STAGE set) */
+	uint32_t add_launches;       /* launches of the adding kernel */
+	uint32_t allocations;        /* device allocations, streams and events this call created (0 once dst has served a call of this shape) */
+	uint32_t pad;
+	uint64_t bytes_over_links;   /* film bytes read or copied from other GPUs */
+} PtxFrameReduceInfo;
+int ptx_frame_reduce_info(ptx_frame_t dst, PtxFrameReduceInfo* out);
+/* The same sums as RCCL collectives over xGMI, for a process that drives several GPUs (one host thread and scene per
+ * GPU, as PT::Pathtracer::set_devices does).  ptx_comm_create makes one RCCL rank per listed GPU (ncclCommInitAll;
+ * every GPU at most once); RCCL itself is loaded at the first call, from the copy the process already holds (PyTorch
+ * ships one) or else from the ROCm installation, PTX_RCCL_LIB overriding both.
+ * ptx_frame_reduce_rccl: dst = sum of parts (NOT added to what dst held), parts[i] on the communicator's i-th GPU, dst
+ * on one of those GPUs; dst may be one of the parts.  One ncclReduce of int64[3*W*H] and one of uint32[W*H] per rank
+ * in one group.  ptx_frame_allreduce: every film ends holding the sum of all (ncclAllReduce in place) -- the exchange
+ * ranks in separate processes perform through torch.distributed.  Both return when the result is complete.
+ * They stand where the reference adds a tile under its mutex (pathtracer.cpp:407-427, 566-584). */
+typedef struct PtxComm* ptx_comm_t;
+int ptx_comm_create(const int* devices, uint32_t n_devices, ptx_comm_t* out);
+uint32_t ptx_comm_size(ptx_comm_t comm);
+const char* ptx_comm_library(ptx_comm_t comm);       /* the RCCL library file in use */
+void ptx_comm_destroy(ptx_comm_t comm);
+int ptx_frame_reduce_rccl(ptx_comm_t comm, ptx_frame_t dst, const ptx_frame_t* parts, uint32_t n_parts);
+int ptx_frame_allreduce(ptx_comm_t comm, const ptx_frame_t* frames, uint32_t n_frames);
 void ptx_frame_destroy(ptx_frame_t frame);
 
 /* Pathtracer::render's tile list (pathtracer.cpp:522-563): 100x100-pixel x 50-sample tiles,
@@ -354,7 +389,14 @@ typedef struct PtxCounters {
 	uint64_t rays_closest;   /* closest-hit queries since the scene was created */
 	uint64_t rays_any;       /* occlusion queries */
 	uint64_t paths;          /* camera samples traced by ptx_render_tiles */
+	/* Rays ptx_render_tiles traced for those paths, counted on the device: camera and scattered ("indirect") rays, and
+	 * direct-lighting rays (pathtracer.cpp:64-76).  The reference traces 1 + 2 per scattering vertex; rays whose answer
+	 * cannot reach the image are left out unless PTX_RENDER_TRACE_UNUSED_RAYS is set.  Shadow rays of delta lights
+	 * (pathtracer.cpp:657) are not included. */
+	uint64_t render_main_rays;
+	uint64_t render_direct_rays;
 } PtxCounters;
+/* Waits for the scene's stream when a render has run (the ray totals are read back from the device). */
 int ptx_get_counters(ptx_scene_t scene, PtxCounters* out);
 /* Device time of the single-mesh traversal kernel (the dominant kernel of ptx_trace_closest /
  * ptx_trace_any on a ptx_scene_create_mesh scene), from HIP events recorded on the scene's stream

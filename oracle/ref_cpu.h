@@ -975,6 +975,7 @@ struct Shading {
 
 struct PathStats {
 	uint64_t rays = 0, shadow_rays = 0;
+	Counters visits;   // nodes tested and Triangle::hit calls of all those rays (reference visit semantics)
 };
 
 struct Pathtracer {
@@ -992,7 +993,7 @@ struct Pathtracer {
 			if (luma(attenuation) == 0.0f) continue;
 			Ray shadow_ray(hit.pos, incoming.direction, V2{EPS_F, incoming.distance - EPS_F});
 			if (stats) stats->shadow_rays++;
-			Trace shadow = scene->hit(shadow_ray);
+			Trace shadow = scene->hit(shadow_ray, stats ? &stats->visits : nullptr);
 			if (!shadow.hit) radiance = radiance + attenuation * incoming.radiance;
 		}
 		return radiance;
@@ -1023,7 +1024,7 @@ struct Pathtracer {
 
 	std::pair<Spec, Spec> trace(RNG& rng, const Ray& ray) const {  // pathtracer.cpp:126-173
 		if (stats) stats->rays++;
-		Trace result = scene->hit(ray);
+		Trace result = scene->hit(ray, stats ? &stats->visits : nullptr);
 		if (!result.hit) {
 			if (!scene->env_lights.empty()) {
 				Spec radiance;

@@ -260,7 +260,7 @@ uint32_t orc_make_tiles(uint32_t w, uint32_t hgt, uint32_t samples, uint32_t fix
 }
 
 // rng_mode 0 = per-tile mt19937 (reference), 1 = Philox per (pixel, sample) keyed by `seed`.
-// stats (2 x uint64, optional): trace() calls, shadow rays.
+// stats (4 x uint64, optional): trace() calls, shadow rays, and the nodes tested / Triangle::hit calls of all of them.
 void orc_render_tiles(void* h, const PtxCamera* cam, const PtxTile* tiles, uint32_t n_tiles, int rng_mode, uint64_t seed,
                       int64_t* accum_rgb, uint32_t* samples, uint64_t* stats, int nthreads) {
 	auto* s = static_cast<OScene*>(h);
@@ -298,8 +298,8 @@ void orc_render_tiles(void* h, const PtxCamera* cam, const PtxTile* tiles, uint3
 		for (size_t i = 0; i < npix; i++) samples[i] += a.samples[i];
 	}
 	if (stats) {
-		stats[0] = stats[1] = 0;
-		for (auto& x : st) stats[0] += x.rays, stats[1] += x.shadow_rays;
+		stats[0] = stats[1] = stats[2] = stats[3] = 0;
+		for (auto& x : st) stats[0] += x.rays, stats[1] += x.shadow_rays, stats[2] += x.visits.nodes, stats[3] += x.visits.tris;
 	}
 }
 

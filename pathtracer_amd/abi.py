@@ -100,7 +100,13 @@ class PtxTile(C.Structure):
 
 
 class PtxCounters(C.Structure):
-    _fields_ = [("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("paths", C.c_uint64)]
+    _fields_ = [("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("paths", C.c_uint64),
+                ("render_main_rays", C.c_uint64), ("render_direct_rays", C.c_uint64)]
+
+
+class PtxFrameReduceInfo(C.Structure):
+    _fields_ = [("parts_local", C.c_uint32), ("parts_peer_direct", C.c_uint32), ("parts_staged", C.c_uint32), ("add_launches", C.c_uint32),
+                ("allocations", C.c_uint32), ("pad", C.c_uint32), ("bytes_over_links", C.c_uint64)]
 
 
 IDENTITY16 = (1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0)

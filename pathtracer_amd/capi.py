@@ -62,6 +62,7 @@ def lib():
     L.ptx_scene_mesh_num_nodes.argtypes = [vp, C.c_uint32]
     L.ptx_scene_mesh_get_nodes.argtypes = [vp, C.c_uint32, vp]
     L.ptx_scene_mesh_get_order.argtypes = [vp, C.c_uint32, vp]
+    L.ptx_scene_mesh_built_on_device.argtypes = [vp, C.c_uint32]
     L.ptx_scene_get_instance_order.argtypes = [vp, vp]
     L.ptx_trace_closest.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint32]
     L.ptx_trace_closest_noalloc.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint32]
@@ -78,6 +79,27 @@ def lib():
     L.ptx_accumulator_to_image.argtypes = [vp, vp, C.c_uint64, vp]
     L.ptx_tonemap.argtypes = [vp, C.c_uint64, C.c_float, vp]
     L.ptx_get_counters.argtypes = [vp, C.POINTER(abi.PtxCounters)]
+    L.ptx_frame_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.ptx_frame_accum.restype = vp
+    L.ptx_frame_accum.argtypes = [vp]
+    L.ptx_frame_samples.restype = vp
+    L.ptx_frame_samples.argtypes = [vp]
+    L.ptx_frame_upload.argtypes = [vp, vp, vp]
+    L.ptx_frame_download.argtypes = [vp, vp, vp]
+    L.ptx_frame_clear.argtypes = [vp]
+    L.ptx_frame_reduce.argtypes = [vp, C.POINTER(vp), C.c_uint32]
+    L.ptx_frame_reduce_info.argtypes = [vp, C.POINTER(abi.PtxFrameReduceInfo)]
+    L.ptx_frame_destroy.argtypes = [vp]
+    L.ptx_frame_destroy.restype = None
+    L.ptx_comm_create.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]
+    L.ptx_comm_size.restype = C.c_uint32
+    L.ptx_comm_size.argtypes = [vp]
+    L.ptx_comm_library.restype = C.c_char_p
+    L.ptx_comm_library.argtypes = [vp]
+    L.ptx_comm_destroy.argtypes = [vp]
+    L.ptx_comm_destroy.restype = None
+    L.ptx_frame_reduce_rccl.argtypes = [vp, vp, C.POINTER(vp), C.c_uint32]
+    L.ptx_frame_allreduce.argtypes = [vp, C.POINTER(vp), C.c_uint32]
     L.ptx_get_kernel_times.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.ptx_js3d_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.ptx_js3d_free.argtypes = [vp]
@@ -212,6 +234,9 @@ class Scene:
         check(lib().ptx_scene_mesh_get_order(self.h, mesh, out.ctypes.data))
         return out
 
+    def mesh_built_on_device(self, mesh=0):
+        return bool(lib().ptx_scene_mesh_built_on_device(self.h, mesh))
+
     def instance_order(self, n):
         out = np.zeros(n, dtype=np.uint32)
         check(lib().ptx_scene_get_instance_order(self.h, out.ctypes.data))
@@ -283,6 +308,83 @@ class Scene:
         c = abi.PtxCounters()
         check(lib().ptx_get_counters(self.h, C.byref(c)))
         return c
+
+
+class Frame:
+    """A film resident on a scene's GPU (ptx_frame_t): Pathtracer::accumulator / accumulator_samples (pathtracer.h:80-83)."""
+
+    def __init__(self, scene, width, height):
+        self.h = vp()
+        self.scene, self.n_pixels = scene, width * height
+        check(lib().ptx_frame_create(scene.h, width, height, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().ptx_frame_destroy(self.h)
+            self.h = vp()
+
+    __del__ = close
+
+    def render_tiles(self, cam, tiles, seed, flags=0):
+        """ptx_render_tiles into this film (device pointers, nothing crosses PCIe)."""
+        tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
+        check(lib().ptx_render_tiles(self.scene.h, C.byref(cam), tiles.ctypes.data, len(tiles), seed, lib().ptx_frame_accum(self.h), lib().ptx_frame_samples(self.h),
+                                     flags | abi.PTX_MEM_DEVICE))
+
+    def upload(self, accum, samples):
+        accum, samples = np.ascontiguousarray(accum, dtype=np.int64), np.ascontiguousarray(samples, dtype=np.uint32)
+        assert accum.size == 3 * self.n_pixels and samples.size == self.n_pixels
+        check(lib().ptx_frame_upload(self.h, accum.ctypes.data, samples.ctypes.data))
+
+    def download(self):
+        accum, samples = np.zeros(3 * self.n_pixels, dtype=np.int64), np.zeros(self.n_pixels, dtype=np.uint32)
+        check(lib().ptx_frame_download(self.h, accum.ctypes.data, samples.ctypes.data))
+        return accum, samples
+
+    def clear(self):
+        check(lib().ptx_frame_clear(self.h))
+
+    def reduce(self, parts):
+        """self += sum of parts (ptx_frame_reduce); returns what the call did (PtxFrameReduceInfo)."""
+        arr = (vp * max(1, len(parts)))(*[p.h for p in parts])
+        check(lib().ptx_frame_reduce(self.h, arr, len(parts)))
+        info = abi.PtxFrameReduceInfo()
+        check(lib().ptx_frame_reduce_info(self.h, C.byref(info)))
+        return info
+
+
+class Comm:
+    """One RCCL rank per listed GPU of this process (ptx_comm_t)."""
+
+    def __init__(self, devices):
+        self.h = vp()
+        arr = (C.c_int * len(devices))(*devices)
+        check(lib().ptx_comm_create(arr, len(devices), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().ptx_comm_destroy(self.h)
+            self.h = vp()
+
+    __del__ = close
+
+    @property
+    def size(self):
+        return lib().ptx_comm_size(self.h)
+
+    @property
+    def library(self):
+        return lib().ptx_comm_library(self.h).decode()
+
+    def reduce(self, dst, parts):
+        """dst = sum of parts (ncclReduce to the rank on dst's GPU)."""
+        arr = (vp * len(parts))(*[p.h for p in parts])
+        check(lib().ptx_frame_reduce_rccl(self.h, dst.h, arr, len(parts)))
+
+    def allreduce(self, frames):
+        """Every film ends holding the sum of all (ncclAllReduce in place)."""
+        arr = (vp * len(frames))(*[f.h for f in frames])
+        check(lib().ptx_frame_allreduce(self.h, arr, len(frames)))
 
 
 class Js3d:

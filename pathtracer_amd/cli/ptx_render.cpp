@@ -2,8 +2,9 @@
 //   -s,--scene FILE  -c,--camera NAME  -o,--output FILE.png  --trace  --no_bvh  --exposure F  --seed N
 //   --film-width N  --film-height N  --film-samples N  --film-max-ray-depth N
 // plus  --device N  (one GPU),  --devices N  (GPUs 0..N-1: tiles dealt across them, films added at the end;
-// --devices a,b,c names them)  and  --fresnel gcc|float  (which behaviour of Materials::schlick to reproduce,
-// scene/material.cpp:58-71).  Exit codes follow the reference: 0 on success, 1 on any reported error.
+// --devices a,b,c names them),  --reduce peer|rccl  (how the GPUs' films are added: the first GPU reading the others'
+// films over their links, or ncclReduce over a communicator with one rank per GPU; same frame bit for bit)  and
+// --fresnel gcc|float  (which behaviour of Materials::schlick to reproduce, scene/material.cpp:58-71).  Exit codes follow the reference: 0 on success, 1 on any reported error.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -19,11 +20,11 @@
 
 static void usage() {
 	std::cerr << "usage: ptx_render --trace -s scene.js3d -c camera_instance [-o out.png] [--no_bvh] [--exposure f] [--seed n]\n"
-	             "                  [--film-width n] [--film-height n] [--film-samples n] [--film-max-ray-depth n] [--device n | --devices n | --devices a,b,..] [--fresnel gcc|float]\n";
+	             "                  [--film-width n] [--film-height n] [--film-samples n] [--film-max-ray-depth n] [--device n | --devices n | --devices a,b,..] [--reduce peer|rccl] [--fresnel gcc|float]\n";
 }
 
 int main(int argc, char** argv) {
-	std::string scene_file, camera_name, output_file, fresnel = "gcc";
+	std::string scene_file, camera_name, output_file, fresnel = "gcc", reduce = "peer";
 	bool pathtrace = false, no_bvh = false;
 	float exposure = 1.0f;
 	uint32_t seed = 0, film_width = -1U, film_height = -1U, film_samples = -1U, film_max_ray_depth = -1U;
@@ -67,6 +68,13 @@ int main(int argc, char** argv) {
 			}
 		}
 		else if (a == "--fresnel") fresnel = value();
+		else if (a == "--reduce") {
+			reduce = value();
+			if (reduce != "peer" && reduce != "rccl") {
+				std::cerr << "ERROR: --reduce takes peer or rccl." << std::endl;
+				return 1;
+			}
+		}
 		else if (a == "-h" || a == "--help") {
 			usage();
 			return 0;
@@ -124,6 +132,7 @@ int main(int argc, char** argv) {
 	std::printf("Render settings:\n\twidth: %u\n\theight: %u\n\texposure: %f\n\tseed: 0x%X\n\tsamples: %u\n\tmax depth: %u\n\tdevices:", cam.film_width,
 	            cam.film_height, exposure, seed, cam.film_samples, cam.film_max_ray_depth);
 	for (int d : devices) std::printf(" %d", d);
+	if (devices.size() > 1) std::printf("\n\tfilm reduce: %s", reduce.c_str());
 	std::printf("\n");
 	if (no_bvh) std::printf("\tusing object list instead of BVH\n");
 	std::printf("\tpathtracing...\n");
@@ -136,6 +145,7 @@ int main(int argc, char** argv) {
 	try {
 		PT::Pathtracer pathtracer;
 		pathtracer.set_devices(devices);
+		pathtracer.set_reduce(reduce == "rccl" ? PT::Pathtracer::Reduce::Rccl : PT::Pathtracer::Reduce::Peer);
 		pathtracer.set_seed(seed);
 		pathtracer.use_bvh(!no_bvh);
 		pathtracer.render(*ptx_js3d_scene_desc(js), cam,

@@ -356,6 +356,7 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 	rec.n_tris = m.n_tris;
 	rec.is_list = m.use_bvh ? 0 : 1;
 	HostBvh bvh;
+	bool on_device = false;   // the tree came from the GPU builder
 	std::vector<float> boxes;
 	BuildLaps laps;
 	triangle_boxes(m.verts, m.indices, m.n_tris, boxes);
@@ -369,14 +370,28 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 	} else if (m.use_bvh) {
 		// Large meshes are built on the GPU the scene lives on (the same tree, byte for byte; a few times faster);
 		// PTX_GPU_BUILD=0 keeps the host builder, =1 sends every mesh to the GPU.
-		static const int gpu_build = getenv("PTX_GPU_BUILD") ? atoi(getenv("PTX_GPU_BUILD")) : -1;
+		const int gpu_build = getenv("PTX_GPU_BUILD") ? atoi(getenv("PTX_GPU_BUILD")) : -1;
 		const uint32_t leaf = m.max_leaf_size ? m.max_leaf_size : 4;
+		bool built = false;
 		if (gpu_build == 1 || (gpu_build != 0 && m.n_tris >= (1u << 17))) {
-			bool on_device = false;
-			if (int rc = build_bvh_gpu(s->device, boxes.data(), m.n_tris, leaf, bvh, on_device)) return rc;
-		} else {
-			build_bvh(boxes.data(), m.n_tris, leaf, bvh);
+			// test switch: make the GPU builder's attempt fail as an out-of-memory device would
+			const bool force_fail = getenv("PTX_GPU_BUILD_FORCE_FAIL") && atoi(getenv("PTX_GPU_BUILD_FORCE_FAIL")) != 0;
+			const int rc = force_fail ? fail(PTX_ERR_OOM, "GPU builder: forced failure (PTX_GPU_BUILD_FORCE_FAIL)") : build_bvh_gpu(s->device, boxes.data(), m.n_tris, leaf, bvh, on_device);
+			if (rc == PTX_OK) {
+				built = true;
+			} else if (gpu_build == 1) {
+				return rc;   // the caller asked for the GPU builder: its failure is the call's failure
+			} else {
+				// The GPU builder needs about 240 B of transient device memory per primitive; on a GPU that is already
+				// full (render state, other scenes) it can fail where the host builder, which gives the same tree byte
+				// for byte, cannot.  It was this library's choice, not the caller's: fall back.
+				(void)hipGetLastError();
+				set_error("");
+				bvh = HostBvh{};
+				on_device = false;
+			}
 		}
+		if (!built) build_bvh(boxes.data(), m.n_tris, leaf, bvh);
 	} else {
 		bvh.order.resize(m.n_tris);
 		for (uint32_t i = 0; i < m.n_tris; i++) bvh.order[i] = i;
@@ -440,6 +455,7 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 	laps.lap("mesh: triangle records");
 	sb.meshes.push_back(rec);
 	s->mesh_bvhs.push_back(std::move(bvh));
+	s->mesh_built_on_device.push_back(on_device ? 1 : 0);
 	return PTX_OK;
 }
 
@@ -977,6 +993,9 @@ int ptx_scene_mesh_get_nodes(ptx_scene_t s, uint32_t mesh, PtxBvhNode* out) {
 	std::copy(s->mesh_bvhs[mesh].nodes.begin(), s->mesh_bvhs[mesh].nodes.end(), out);
 	return PTX_OK;
 }
+int ptx_scene_mesh_built_on_device(ptx_scene_t s, uint32_t mesh) {
+	return (s && mesh < s->mesh_built_on_device.size()) ? int(s->mesh_built_on_device[mesh]) : 0;
+}
 int ptx_scene_mesh_get_order(ptx_scene_t s, uint32_t mesh, uint32_t* out) {
 	if (!s || !out || mesh >= s->mesh_bvhs.size()) return fail(PTX_ERR_INVALID, "ptx_scene_mesh_get_order: bad argument");
 	std::copy(s->mesh_bvhs[mesh].order.begin(), s->mesh_bvhs[mesh].order.end(), out);
@@ -1005,6 +1024,13 @@ int ptx_get_kernel_times(ptx_scene_t s, float* ms, uint32_t cap, uint32_t* n_out
 int ptx_get_counters(ptx_scene_t s, PtxCounters* out) {
 	if (!s || !out) return fail(PTX_ERR_INVALID, "ptx_get_counters: null argument");
 	*out = s->counters;
+	if (s->scratch[9]) {   // the render's ray totals live on the device (render.hip, k_round_tally)
+		unsigned long long t[2] = {};
+		PTX_HIP(hipSetDevice(s->device));
+		PTX_HIP(hipMemcpyAsync(t, s->scratch[9], sizeof(t), hipMemcpyDeviceToHost, s->stream));
+		PTX_HIP(hipStreamSynchronize(s->stream));
+		out->render_main_rays = t[0], out->render_direct_rays = t[1];
+	}
 	return PTX_OK;
 }
 

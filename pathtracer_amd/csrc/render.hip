@@ -588,6 +588,16 @@ __global__ void __launch_bounds__(256) k_flush(RenderBuffers rb, uint32_t n_slot
 	atomicAdd(&samples[si.pixel], si.s_count);
 }
 
+// Between an extend round and its shade launch: the rays that round traced are added to the scene's running totals
+// (ptx_get_counters), the list the shade stage is about to fill and the direct-ray list just consumed are emptied.
+__global__ void k_round_tally(uint32_t* __restrict__ counts, uint32_t cur, uint32_t main_traced, unsigned long long* __restrict__ tally) {
+	if (blockIdx.x || threadIdx.x) return;
+	tally[0] += main_traced ? counts[cur] : 0u;
+	tally[1] += counts[2];
+	counts[cur ^ 1u] = 0u;
+	counts[2] = 0u;
+}
+
 // Known-answer access to the random stream: one Philox block per thread.
 __global__ void k_philox_blocks(const uint32_t* __restrict__ counters, const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ out) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -730,8 +740,11 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		const dim3 block(256), grid_slots((ns + 255) / 256), grid_items((2 * n_paths + 255) / 256);
 		// Small batches (a 256x256 film is 65k paths, 8 waves per CU) do not fill the replenishing kernel's
 		// waves for long enough to pay for its set-up launches: they keep one ray per lane.
-		static const bool count_rays = getenv("PTX_RENDER_COUNT_RAYS") && atoi(getenv("PTX_RENDER_COUNT_RAYS")) != 0;
-		uint64_t n_main_rays = 0, n_direct_rays = 0;
+		if (!s->scratch[9]) {   // running totals of the rays the extend rounds trace: main rays, direct rays
+			if (int rc = device_alloc(s, 9, 4 * sizeof(unsigned long long), &p)) return rc;
+			PTX_HIP(hipMemsetAsync(s->scratch[9], 0, 4 * sizeof(unsigned long long), s->stream));
+		}
+		unsigned long long* const ray_tally = static_cast<unsigned long long*>(s->scratch[9]);
 		const bool reference_order = (flags & PTX_RENDER_REFERENCE_ORDER) != 0;
 		const bool trace_unused = (flags & PTX_RENDER_TRACE_UNUSED_RAYS) != 0;
 		ShadeTables shade_tables = s->shade;
@@ -749,12 +762,6 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 				// ray): no hit of theirs is used, only the direct rays are traced.
 				const bool last_vertex_round = round == cam->film_max_ray_depth && round > 0;
 				const RenderIO io{rb, rb.active[cur], rb.counts + cur, (last_vertex_round && !trace_unused) ? 0u : 1u};
-				if (count_rays) {   // diagnostic (PTX_RENDER_COUNT_RAYS=1): rays this round traces, read back with a stream sync
-					uint32_t c[3];
-					PTX_HIP(hipMemcpyAsync(c, rb.counts, sizeof(c), hipMemcpyDeviceToHost, s->stream));
-					PTX_HIP(hipStreamSynchronize(s->stream));
-					n_main_rays += io.main_rays ? c[cur] : 0u, n_direct_rays += c[2];
-				}
 				if (persistent) {
 					if (int rc = launch_scene_persistent(s, io, 2 * n_paths)) return rc;
 				} else if (reference_order) {
@@ -762,8 +769,8 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 				} else {
 					hipLaunchKernelGGL(k_extend<MODE_CULLED>, grid_items, block, 0, s->stream, s->rec, io);
 				}
-				PTX_HIP(hipMemsetAsync(rb.counts + (cur ^ 1), 0, sizeof(uint32_t), s->stream));
-				PTX_HIP(hipMemsetAsync(rb.counts + 2, 0, sizeof(uint32_t), s->stream));   // the direct rays just traced are consumed; k_shade lists the next ones
+				// the direct rays just traced are consumed; k_shade lists the next ones and the next active list
+				hipLaunchKernelGGL(k_round_tally, dim3(1), dim3(64), 0, s->stream, rb.counts, uint32_t(cur), io.main_rays, ray_tally);
 				const bool delta = n_lights != 0;
 				const auto shade = delta ? k_shade<true> : k_shade<false>;
 				hipLaunchKernelGGL(shade, dim3((np + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->rec, shade_tables, rb, rb.active[cur], rb.counts + cur, k, key0, key1,
@@ -790,9 +797,6 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		uint64_t chunk_paths = 0;
 		for (const TileRec& t : chunk) chunk_paths += uint64_t(t.w) * t.h * t.s_count;
 		s->counters.paths += chunk_paths;
-		if (count_rays)
-			std::fprintf(stderr, "[render rays] %llu paths: %llu main rays, %llu direct rays traced (%.2f rays per path)\n", (unsigned long long)chunk_paths, (unsigned long long)n_main_rays,
-			             (unsigned long long)n_direct_rays, double(n_main_rays + n_direct_rays) / double(chunk_paths ? chunk_paths : 1));
 	}
 #ifdef PTX_PROFILE_SHADE
 	{
@@ -848,137 +852,4 @@ extern "C" int ptx_selftest_path_units(int device, uint64_t seed, uint32_t pixel
 	(void)hipFree(d);
 	if (e != hipSuccess) return hip_fail(e, "ptx_selftest_path_units");
 	return PTX_OK;
-}
-
-// ------------------------------------------------------------------ device-resident film
-struct PtxFrame {
-	PtxScene* scene;
-	size_t n_pixels;
-	int64_t* accum;
-	uint32_t* samples;
-};
-
-extern "C" int ptx_frame_create(ptx_scene_t s, uint32_t width, uint32_t height, ptx_frame_t* out) {
-	if (!s || !out || !width || !height) return fail(PTX_ERR_INVALID, "ptx_frame_create: null argument or empty film");
-	PTX_HIP(hipSetDevice(s->device));
-	PtxFrame* f = new PtxFrame{s, size_t(width) * height, nullptr, nullptr};
-	const size_t a_bytes = f->n_pixels * 3 * sizeof(int64_t), s_bytes = f->n_pixels * sizeof(uint32_t);
-	void* p = nullptr;
-	if (hipMalloc(&p, a_bytes + s_bytes) != hipSuccess) {
-		delete f;
-		return fail(PTX_ERR_OOM, "ptx_frame_create: out of device memory");
-	}
-	f->accum = static_cast<int64_t*>(p);
-	f->samples = reinterpret_cast<uint32_t*>(static_cast<char*>(p) + a_bytes);
-	if (hipMemsetAsync(p, 0, a_bytes + s_bytes, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) {
-		(void)hipFree(p);
-		delete f;
-		return fail(PTX_ERR_DEVICE, "ptx_frame_create: clearing the film failed");
-	}
-	*out = f;
-	return PTX_OK;
-}
-extern "C" int64_t* ptx_frame_accum(ptx_frame_t f) { return f ? f->accum : nullptr; }
-extern "C" uint32_t* ptx_frame_samples(ptx_frame_t f) { return f ? f->samples : nullptr; }
-extern "C" int ptx_frame_upload(ptx_frame_t f, const int64_t* accum_rgb, const uint32_t* samples) {
-	if (!f || !accum_rgb || !samples) return fail(PTX_ERR_INVALID, "ptx_frame_upload: null argument");
-	PTX_HIP(hipSetDevice(f->scene->device));
-	PTX_HIP(hipMemcpyAsync(f->accum, accum_rgb, f->n_pixels * 3 * sizeof(int64_t), hipMemcpyHostToDevice, f->scene->stream));
-	PTX_HIP(hipMemcpyAsync(f->samples, samples, f->n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, f->scene->stream));
-	PTX_HIP(hipStreamSynchronize(f->scene->stream));
-	return PTX_OK;
-}
-extern "C" int ptx_frame_download(ptx_frame_t f, int64_t* accum_rgb, uint32_t* samples) {
-	if (!f || !accum_rgb || !samples) return fail(PTX_ERR_INVALID, "ptx_frame_download: null argument");
-	PTX_HIP(hipSetDevice(f->scene->device));
-	PTX_HIP(hipMemcpyAsync(accum_rgb, f->accum, f->n_pixels * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, f->scene->stream));
-	PTX_HIP(hipMemcpyAsync(samples, f->samples, f->n_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, f->scene->stream));
-	PTX_HIP(hipStreamSynchronize(f->scene->stream));
-	return PTX_OK;
-}
-extern "C" int ptx_frame_clear(ptx_frame_t f) {
-	if (!f) return fail(PTX_ERR_INVALID, "ptx_frame_clear: null frame");
-	PTX_HIP(hipSetDevice(f->scene->device));
-	PTX_HIP(hipMemsetAsync(f->accum, 0, f->n_pixels * (3 * sizeof(int64_t) + sizeof(uint32_t)), f->scene->stream));
-	PTX_HIP(hipStreamSynchronize(f->scene->stream));
-	return PTX_OK;
-}
-
-namespace ptx {
-// dst += src for one film: 3 int64 sums and one sample count per pixel (integer adds: any order gives the same frame).
-__global__ void __launch_bounds__(256) k_frame_add(unsigned long long* __restrict__ dst_acc, const unsigned long long* __restrict__ src_acc,
-                                                   uint32_t* __restrict__ dst_smp, const uint32_t* __restrict__ src_smp, size_t n_pixels) {
-	const size_t stride = size_t(gridDim.x) * blockDim.x;
-	for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_pixels * 3; i += stride) dst_acc[i] += src_acc[i];
-	for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_pixels; i += stride) dst_smp[i] += src_smp[i];
-}
-}  // namespace ptx
-
-extern "C" int ptx_frame_reduce(ptx_frame_t dst, const ptx_frame_t* parts, uint32_t n_parts) {
-	if (!dst || (n_parts && !parts)) return fail(PTX_ERR_INVALID, "ptx_frame_reduce: null argument");
-	for (uint32_t i = 0; i < n_parts; i++) {
-		if (!parts[i] || parts[i] == dst) return fail(PTX_ERR_INVALID, "ptx_frame_reduce: a part is null or is the destination itself");
-		if (parts[i]->n_pixels != dst->n_pixels) return fail(PTX_ERR_INVALID, "ptx_frame_reduce: films of different sizes");
-	}
-	if (n_parts == 0) return PTX_OK;
-	const int dev = dst->scene->device;
-	hipStream_t stream = dst->scene->stream;
-	PTX_HIP(hipSetDevice(dev));
-	const size_t bytes = dst->n_pixels * (3 * sizeof(int64_t) + sizeof(uint32_t));
-	const size_t a_bytes = dst->n_pixels * 3 * sizeof(int64_t);
-	const dim3 block(256), grid(uint32_t(std::min<size_t>((dst->n_pixels * 3 + 255) / 256, 256 * 64)));
-	auto add = [&](const void* film) -> hipError_t {
-		hipLaunchKernelGGL(k_frame_add, grid, block, 0, stream, reinterpret_cast<unsigned long long*>(dst->accum), static_cast<const unsigned long long*>(film), dst->samples,
-		                   reinterpret_cast<const uint32_t*>(static_cast<const char*>(film) + a_bytes), dst->n_pixels);
-		return hipGetLastError();
-	};
-	// Parts on the destination's own GPU are added where they lie.  Parts on other GPUs are copied into staging
-	// films on the destination first, a group of them at a time, each copy on a stream of its own: every source
-	// GPU has its own xGMI link to the destination, so the copies of a group run side by side (a film is one
-	// allocation, sums then counts: one copy; hipMemcpyPeer goes through the host where two GPUs have no direct path).
-	std::vector<const PtxFrame*> remote;
-	hipError_t e = hipSuccess;
-	// test switch: stage same-device parts too, so that one GPU exercises the copy path
-	const bool stage_all = getenv("PTX_FRAME_REDUCE_STAGE") && atoi(getenv("PTX_FRAME_REDUCE_STAGE")) != 0;
-	for (uint32_t i = 0; i < n_parts && e == hipSuccess; i++) {
-		if (parts[i]->scene->device == dev && !stage_all) e = add(parts[i]->accum);
-		else remote.push_back(parts[i]);
-	}
-	const size_t group = std::max<size_t>(1, std::min<size_t>(remote.size(), (size_t(4) << 30) / bytes));   // at most 4 GB of staging films
-	void* staging = nullptr;
-	std::vector<hipStream_t> copy_streams;
-	std::vector<hipEvent_t> copied;
-	if (e == hipSuccess && !remote.empty()) e = hipMalloc(&staging, group * bytes);
-	for (size_t k = 0; k < group && e == hipSuccess && !remote.empty(); k++) {
-		hipStream_t st = nullptr;
-		hipEvent_t ev = nullptr;
-		e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-		if (e == hipSuccess) copy_streams.push_back(st), e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-		if (e == hipSuccess) copied.push_back(ev);
-	}
-	for (size_t first = 0; first < remote.size() && e == hipSuccess; first += group) {
-		const size_t count = std::min(group, remote.size() - first);
-		for (size_t k = 0; k < count && e == hipSuccess; k++) {
-			char* film = static_cast<char*>(staging) + k * bytes;
-			e = hipMemcpyPeerAsync(film, dev, remote[first + k]->accum, remote[first + k]->scene->device, bytes, copy_streams[k]);
-			if (e == hipSuccess) e = hipEventRecord(copied[k], copy_streams[k]);
-		}
-		for (size_t k = 0; k < count && e == hipSuccess; k++) {
-			e = hipStreamWaitEvent(stream, copied[k], 0);
-			if (e == hipSuccess) e = add(static_cast<char*>(staging) + k * bytes);
-		}
-		if (e == hipSuccess) e = hipStreamSynchronize(stream);   // the staging films are reused by the next group
-	}
-	if (e == hipSuccess) e = hipStreamSynchronize(stream);
-	for (hipStream_t st : copy_streams) (void)hipStreamSynchronize(st), (void)hipStreamDestroy(st);
-	for (hipEvent_t ev : copied) (void)hipEventDestroy(ev);
-	if (staging) (void)hipFree(staging);
-	return e == hipSuccess ? PTX_OK : hip_fail(e, "ptx_frame_reduce");
-}
-
-extern "C" void ptx_frame_destroy(ptx_frame_t f) {
-	if (!f) return;
-	(void)hipSetDevice(f->scene->device);
-	(void)hipFree(f->accum);
-	delete f;
 }

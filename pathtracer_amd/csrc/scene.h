@@ -83,6 +83,7 @@ struct PtxScene {
 	ptx::ShadeTables shade{};
 	std::vector<void*> allocations; // everything hipMalloc'ed for this scene
 	std::vector<ptx::HostBvh> mesh_bvhs;
+	std::vector<uint8_t> mesh_built_on_device;   // per mesh: 1 when its tree came from the GPU builder
 	ptx::HostBvh top_bvh;
 	uint32_t stack_need = 0;        // deepest stack a traversal of this scene can need
 	uint32_t cu_count = 256;

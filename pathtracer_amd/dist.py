@@ -47,9 +47,11 @@ def reduce_frame(accum, samples, group=None):
     return accum, samples
 
 
-def render_sharded(scene, camera, tiles, seed, rank, world, device=None, group=None):
+def render_sharded(scene, camera, tiles, seed, rank, world, device=None, group=None, timings=None):
     """Renders this rank's share of `tiles` on its GPU and reduces: returns (accum, samples) torch tensors
-    holding the complete frame on every rank."""
+    holding the complete frame on every rank.  `timings` (a dict, optional) receives this rank's `compute_s` (its tiles
+    rendered, device idle again), `reduce_s` (the frame exchange) and `tiles` (how many it was dealt)."""
+    import time
     import torch
     from . import abi
     npix = camera.film_width * camera.film_height
@@ -57,7 +59,13 @@ def render_sharded(scene, camera, tiles, seed, rank, world, device=None, group=N
     accum = torch.zeros(npix * 3, dtype=torch.int64, device=dev)
     samples = torch.zeros(npix, dtype=torch.int32, device=dev)
     mine = np.ascontiguousarray(deal_tiles(np.asarray(tiles), rank, world))
+    t0 = time.perf_counter()
     if len(mine):
         scene.render_tiles(camera, mine, seed, accum, samples, flags=abi.PTX_ASYNC)
     torch.cuda.synchronize(dev)
-    return reduce_frame(accum, samples, group)
+    t1 = time.perf_counter()
+    out = reduce_frame(accum, samples, group)
+    if timings is not None:
+        torch.cuda.synchronize(dev)
+        timings.update(compute_s=t1 - t0, reduce_s=time.perf_counter() - t1, tiles=int(len(mine)))
+    return out

@@ -255,6 +255,11 @@ public:
 		devices = list.empty() ? std::vector<int>{0} : list;
 	}
 	void set_device(int d) { set_devices({d}); }
+	// How the GPUs' films are added: Peer = ptx_frame_reduce (the first GPU reads the others' films over their links),
+	// Rccl = ptx_frame_reduce_rccl (ncclReduce over a communicator with one rank per GPU).  Same frame bit for bit.
+	// Rccl needs every GPU listed once; a list that names a GPU twice uses Peer.
+	enum class Reduce { Peer, Rccl };
+	void set_reduce(Reduce r) { reduce_mode = r; }
 	// RNG::fixed_seed (util/rand.cpp, main.cpp:66).  0 = none: every render() call draws a seed of its own, as the
 	// reference's unseeded RNG does (pathtracer.cpp:533-534).
 	void set_seed(uint32_t fixed_seed) { seed = fixed_seed; }
@@ -365,12 +370,25 @@ private:
 		for (size_t k = 0; ok && k < n_dev; k++) ok = ptx_frame_create(scenes[k], camera.film_width, camera.film_height, &parts[k]) == PTX_OK;
 		if (!ok) note_error();
 		std::shared_mutex films;
-		std::atomic<bool> abort_all{!ok};
+		ptx_comm_t comm = nullptr;
+		if (ok && reduce_mode == Reduce::Rccl) {   // also with one GPU when asked for: a one-rank communicator
+			std::vector<int> sorted = devices;
+			std::sort(sorted.begin(), sorted.end());
+			if (std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end() && ptx_comm_create(devices.data(), uint32_t(n_dev), &comm) != PTX_OK) ok = false, note_error();
+		}
 		auto read_back = [&]() -> bool {   // caller holds `films` exclusively
-			const ptx_frame_t base[1] = {total};
-			return ptx_frame_clear(shown) == PTX_OK && ptx_frame_reduce(shown, base, 1) == PTX_OK && ptx_frame_reduce(shown, parts.data(), uint32_t(n_dev)) == PTX_OK &&
+			if (comm) {   // shown = sum of parts (RCCL), then + total where it lies
+				const ptx_frame_t base[1] = {total};
+				return ptx_frame_reduce_rccl(comm, shown, parts.data(), uint32_t(n_dev)) == PTX_OK && ptx_frame_reduce(shown, base, 1) == PTX_OK &&
+				       ptx_frame_download(shown, accumulator.data(), accumulator_samples.data()) == PTX_OK;
+			}
+			std::vector<ptx_frame_t> all{total};
+			all.insert(all.end(), parts.begin(), parts.end());
+			return ptx_frame_clear(shown) == PTX_OK && ptx_frame_reduce(shown, all.data(), uint32_t(all.size())) == PTX_OK &&
 			       ptx_frame_download(shown, accumulator.data(), accumulator_samples.data()) == PTX_OK;
 		};
+		std::atomic<bool> abort_all{!ok};
+		std::atomic<bool> final_reported{false};
 		auto last_report = std::chrono::steady_clock::now();
 		std::mutex report_mutex;
 		auto device_loop = [&](size_t k) {
@@ -393,8 +411,8 @@ private:
 				std::unique_lock<std::mutex> rl(report_mutex, std::try_to_lock);   // one reporter at a time; the others go on rendering
 				if (!rl.owns_lock()) continue;
 				const auto now = std::chrono::steady_clock::now();
-				const bool last = done >= total_tiles;
-				if (last || std::chrono::duration<float>(now - last_report).count() >= report_interval) {
+				if (done >= total_tiles) continue;   // the report at 1.0 comes from run(), after every worker has finished
+				if (std::chrono::duration<float>(now - last_report).count() >= report_interval) {
 					std::unique_lock<std::shared_mutex> lock(films);
 					if (!read_back()) {
 						note_error();
@@ -402,7 +420,8 @@ private:
 						break;
 					}
 					lock.unlock();
-					report_fn(Render_Report{float(traced_tiles.load()) / float(total_tiles), accumulator_to_image()});
+					const uint32_t so_far = traced_tiles.load();
+					if (so_far < total_tiles) report_fn(Render_Report{float(so_far) / float(total_tiles), accumulator_to_image()});   // 1.0 is run()'s to report
 					last_report = now;
 				}
 			}
@@ -414,9 +433,16 @@ private:
 			for (auto& t : th) t.join();
 			if (!abort_all) {
 				std::unique_lock<std::shared_mutex> lock(films);
-				if (!read_back()) note_error();
+				if (!read_back()) {
+					note_error();
+				} else if (report_fn && traced_tiles.load() >= total_tiles && !final_reported.exchange(true)) {
+					// the reference ends every finished render with report_fn({1.0f, image}) (pathtracer.cpp:574-579)
+					lock.unlock();
+					report_fn(Render_Report{1.0f, accumulator_to_image()});
+				}
 			}
 		}
+		if (comm) ptx_comm_destroy(comm);
 		failed = first_error;
 		for (ptx_frame_t p : parts) ptx_frame_destroy(p);
 		ptx_frame_destroy(total), ptx_frame_destroy(shown);
@@ -425,6 +451,7 @@ private:
 	}
 
 	bool scene_use_bvh = true;
+	Reduce reduce_mode = Reduce::Peer;
 	std::vector<int> devices{0};
 	uint32_t seed = 1, render_seed = 1, tiles_per_batch = 128;   // 128 tiles of 100x100x50 = 64 M paths, one pass of the library
 	std::vector<ptx_scene_t> scenes;   // one per entry of `devices`

@@ -286,7 +286,7 @@ class OracleScene:
         npix = cam.film_width * cam.film_height
         acc = np.zeros(npix * 3, dtype=np.int64)
         smp = np.zeros(npix, dtype=np.uint32)
-        st = np.zeros(2, dtype=np.uint64) if stats else None
+        st = np.zeros(4, dtype=np.uint64) if stats else None   # trace() calls, shadow rays, nodes tested, Triangle::hit calls
         tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
         self.o.L.orc_render_tiles(self.h, C.byref(cam), tiles.ctypes.data_as(C.POINTER(abi.PtxTile)), len(tiles), rng_mode, seed,
                                   _ptr(acc, i64p), abi.uptr(smp), _ptr(st, u64p), nthreads)

@@ -113,11 +113,23 @@ int main(int argc, char** argv) {
 			PT::Pathtracer three;
 			three.set_devices({0, 0, 0});
 			three.set_report_interval(0.0f);
-			int reports = 0;
-			three.render(desc, cam, [&](PT::Pathtracer::Render_Report&&) { reports++; }, &quit);
+			int reports = 0, final_reports = 0;
+			float last_fraction = 0.0f;
+			three.render(desc, cam, [&](PT::Pathtracer::Render_Report&& r) { reports++, final_reports += r.first == 1.0f, last_fraction = r.first; }, &quit);
 			three.wait();
-			EXPECT(three.error().empty() && reports >= 1);
+			// every finished render ends with exactly one report at 1.0 (pathtracer.cpp:574-579), whichever worker finished last
+			EXPECT(three.error().empty() && reports >= 1 && final_reports == 1 && last_fraction == 1.0f);
 			EXPECT(three.accumulator_rgb() == first_acc);
+			// the films added by RCCL (a one-rank communicator on a one-GPU box) instead of peer reads: same frame
+			PT::Pathtracer rccl;
+			rccl.set_reduce(PT::Pathtracer::Reduce::Rccl);
+			rccl.set_tiles_per_batch(4);
+			rccl.set_report_interval(0.0f);
+			reports = 0;
+			rccl.render(desc, cam, [&](PT::Pathtracer::Render_Report&&) { reports++; }, &quit);
+			rccl.wait();
+			EXPECT(rccl.error().empty() && reports == 5);
+			EXPECT(rccl.accumulator_rgb() == first_acc);
 		}
 
 		// add_samples: the same film gets 60 more samples per pixel -- NEW samples (the sample index continues), so the

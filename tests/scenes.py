@@ -118,20 +118,15 @@ def cow_mesh():
     return g[f"mesh{cow_i}_verts"], g[f"mesh{cow_i}_indices"]
 
 
-def instanced_cows(n):
-    """n^3 rotated instances of the cow mesh on a grid (10.1 M instanced triangles at n = 12), Lambertian, over a
-    floor quad and under one emissive quad; returns (SceneBuilder, PtxCamera without film settings)."""
-    sb = abi.SceneBuilder()
-    cow = sb.add_mesh(*cow_mesh())
-    q = sb.add_mesh(*quad())
-    white = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.7, 0.7, 0.7)))
-    red = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.7, 0.3, 0.3)))
+def cow_grid_transforms(n):
+    """local_to_world of the n^3 cows of the grid scenes, in the order the instances are added."""
+    return [trs((ix * 1.2, iy * 1.2, iz * 1.2), axis=(0, 1, 0), deg=17.0 * (ix + 2 * iy + 3 * iz), scale=(0.9, 0.9, 0.9))
+            for ix in range(n) for iy in range(n) for iz in range(n)]
+
+
+def _cow_grid_room(sb, n, q, white):
+    """Floor, lamp and camera shared by the instanced and the flattened cow grid."""
     lamp = sb.add_material(abi.PTX_MAT_EMISSIVE, sb.add_constant_texture((1, 1, 1), 6.0))
-    for ix in range(n):
-        for iy in range(n):
-            for iz in range(n):
-                sb.add_instance(cow, white if (ix + iy + iz) % 2 else red,
-                                trs((ix * 1.2, iy * 1.2, iz * 1.2), axis=(0, 1, 0), deg=17.0 * (ix + 2 * iy + 3 * iz), scale=(0.9, 0.9, 0.9)))
     L = n * 1.2
     sb.add_instance(q, white, trs((L / 2, -0.8, L / 2), scale=(L, 1, L)))
     sb.add_instance(q, lamp, trs((L / 2, L + 1.0, L / 2), axis=(1, 0, 0), deg=180, scale=(L / 2, 1, L / 2)))
@@ -140,4 +135,95 @@ def instanced_cows(n):
     T = trs((L / 2, L * 0.7, L * 2.4), axis=(1, 0, 0), deg=-12)
     for i in range(16):
         cam.camera_to_world[i] = float(T[i])
+    return cam
+
+
+def instanced_cows(n, two_tone=True):
+    """n^3 rotated instances of the cow mesh on a grid (10.1 M instanced triangles at n = 12), Lambertian (alternating
+    white and red, or all white), over a floor quad and under one emissive quad; returns (SceneBuilder, PtxCamera
+    without film settings)."""
+    sb = abi.SceneBuilder()
+    cow = sb.add_mesh(*cow_mesh())
+    q = sb.add_mesh(*quad())
+    white = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.7, 0.7, 0.7)))
+    red = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.7, 0.3, 0.3)))
+    for k, T in enumerate(cow_grid_transforms(n)):
+        ix, iy, iz = k // (n * n), (k // n) % n, k % n
+        sb.add_instance(cow, white if (ix + iy + iz) % 2 or not two_tone else red, T)
+    cam = _cow_grid_room(sb, n, q, white)
     return sb, cam
+
+
+def flattened_cows(n):
+    """The cow grid of instanced_cows(n) baked into ONE mesh in world space (10,119,168 triangles and 30,357,504
+    vertices at n = 12: about 215 MB of tree nodes, 486 MB of triangle geometry and 607 MB of attributes on the GPU --
+    a tree that lives in HBM, not in the caches).  Vertex k of cow c is vertex c*17568 + k: position = the instance's
+    float32 local_to_world applied in float64 and rounded to float32 once, normal = its rotation applied likewise.
+    Returns (verts, indices)."""
+    cv, ci = cow_mesh()
+    Ts = cow_grid_transforms(n)
+    nv, nt = len(cv), len(ci)
+    verts = np.empty((len(Ts) * nv, 8), dtype=np.float32)
+    idx = np.empty((len(Ts) * nt, 3), dtype=np.uint32)
+    p64, n64 = cv[:, :3].astype(np.float64), cv[:, 3:6].astype(np.float64)
+    for c, T in enumerate(Ts):
+        M = T.astype(np.float64).reshape(4, 4).T          # column-major 16 floats -> row-major 4x4
+        out = verts[c * nv:(c + 1) * nv]
+        out[:, :3] = (p64 @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
+        out[:, 3:6] = (n64 @ (M[:3, :3] / 0.9).T).astype(np.float32)
+        out[:, 6:] = cv[:, 6:]
+        idx[c * nt:(c + 1) * nt] = ci + np.uint32(c * nv)
+    return verts, idx
+
+
+def flattened_cow_scene(n, verts=None, idx=None, nodes=None):
+    """The flattened cow grid as a lit scene: the one big mesh under an identity instance (Lambertian), the floor quad
+    and the emissive quad of instanced_cows; returns (SceneBuilder, PtxCamera without film settings)."""
+    if verts is None:
+        verts, idx = flattened_cows(n)
+    sb = abi.SceneBuilder()
+    big = sb.add_mesh(verts, idx, nodes=nodes)
+    q = sb.add_mesh(*quad())
+    white = sb.add_material(abi.PTX_MAT_LAMBERTIAN, sb.add_constant_texture((0.7, 0.7, 0.7)))
+    sb.add_instance(big, white)
+    cam = _cow_grid_room(sb, n, q, white)
+    return sb, cam
+
+
+# ---- adversarial rays for the culled traversal order: rays that lie (almost) in the plane of a triangle they pass
+def skimming_rays(verts, idx, n, seed, lift):
+    """From just off a random triangle's plane (`lift` x the mesh's size) towards a point of that triangle, along the plane."""
+    g = np.random.Generator(np.random.Philox(key=seed))
+    tri = idx[g.integers(0, len(idx), n)]
+    a, b, c = (verts[tri[:, k], :3].astype(np.float64) for k in range(3))
+    nrm = np.cross(b - a, c - a)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+    w = g.random((n, 3)) + 0.05
+    w /= w.sum(axis=1, keepdims=True)
+    target = a * w[:, :1] + b * w[:, 1:2] + c * w[:, 2:]
+    along = (b - a) * (g.random((n, 1)) * 2 - 1) + (c - a) * (g.random((n, 1)) * 2 - 1)
+    along /= np.maximum(np.linalg.norm(along, axis=1, keepdims=True), 1e-30)
+    size = np.linalg.norm(verts[:, :3].max(axis=0) - verts[:, :3].min(axis=0))
+    o = target - along * (0.05 + g.random((n, 1))) * size * 0.3 + nrm * (g.random((n, 1)) * 2 - 1) * size * lift
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.zeros(n, dtype=abi.RAY_DTYPE)
+    r["o"] = o.astype(np.float32)
+    r["d"] = synth._unit_f32(d)
+    r["tmin"], r["tmax"] = 0.0, np.inf
+    return r
+
+
+def slivers(n, key):
+    """Long thin triangles (aspect 1:200) in random orientations inside a unit cube: many overlap along any line."""
+    g = np.random.Generator(np.random.Philox(key=key))
+    c = g.random((n, 3))
+    u = g.standard_normal((n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = np.cross(u, g.standard_normal((n, 3)))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    p = np.stack([c - u * 0.1, c + u * 0.1, c + v * 0.001], axis=1).reshape(-1, 3)
+    verts = np.zeros((3 * n, 8), dtype=np.float32)
+    verts[:, :3] = p
+    verts[:, 4] = 1.0
+    return verts, np.arange(3 * n, dtype=np.uint32).reshape(n, 3)

@@ -119,3 +119,25 @@ def test_ten_million_boxes():
     host = capi.Bvh(boxes=boxes, max_leaf_size=4)
     gpu = capi.Bvh(boxes=boxes, max_leaf_size=4, gpu_device=0)
     same_tree(host, gpu)
+
+
+def test_scene_creation_falls_back_to_the_host_builder(monkeypatch):
+    """Scene creation sends meshes of 2^17 triangles and more to the GPU builder on its own initiative; when that
+    attempt fails (transient device memory on a full GPU) the host builder, which gives the same tree byte for byte,
+    takes over.  Only an explicit PTX_GPU_BUILD=1 makes the GPU builder's failure the call's failure."""
+    verts, idx = synth.soup(150_000, key=31)
+    rays = synth.rays(1 << 14, key=32)
+    sc = capi.Scene.from_mesh(verts, idx)
+    assert sc.mesh_built_on_device()
+    want_nodes, want = sc.mesh_nodes(), sc.trace_closest(rays)["hits"]
+    sc.close()
+    monkeypatch.setenv("PTX_GPU_BUILD_FORCE_FAIL", "1")
+    sc = capi.Scene.from_mesh(verts, idx)
+    assert not sc.mesh_built_on_device()
+    assert sc.mesh_nodes().tobytes() == want_nodes.tobytes()
+    got = sc.trace_closest(rays)["hits"]
+    assert got.tobytes() == want.tobytes()
+    sc.close()
+    monkeypatch.setenv("PTX_GPU_BUILD", "1")
+    with pytest.raises(capi.PtxError):
+        capi.Scene.from_mesh(verts, idx)

@@ -14,43 +14,7 @@ import scenes
 from pathtracer_amd import abi, capi, synth
 
 
-def grazing(verts, idx, n, seed, lift):
-    """From just off a random triangle's plane (`lift` x the mesh's size) towards a point of that triangle, along the plane."""
-    g = np.random.Generator(np.random.Philox(key=seed))
-    tri = idx[g.integers(0, len(idx), n)]
-    a, b, c = (verts[tri[:, k], :3].astype(np.float64) for k in range(3))
-    nrm = np.cross(b - a, c - a)
-    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
-    w = g.random((n, 3)) + 0.05
-    w /= w.sum(axis=1, keepdims=True)
-    target = a * w[:, :1] + b * w[:, 1:2] + c * w[:, 2:]
-    along = (b - a) * (g.random((n, 1)) * 2 - 1) + (c - a) * (g.random((n, 1)) * 2 - 1)
-    along /= np.maximum(np.linalg.norm(along, axis=1, keepdims=True), 1e-30)
-    size = np.linalg.norm(verts[:, :3].max(axis=0) - verts[:, :3].min(axis=0))
-    o = target - along * (0.05 + g.random((n, 1))) * size * 0.3 + nrm * (g.random((n, 1)) * 2 - 1) * size * lift
-    d = target - o
-    d /= np.linalg.norm(d, axis=1, keepdims=True)
-    r = np.zeros(n, dtype=abi.RAY_DTYPE)
-    r["o"] = o.astype(np.float32)
-    r["d"] = synth._unit_f32(d)
-    r["tmin"], r["tmax"] = 0.0, np.inf
-    return r
-
-
-def slivers(n, key):
-    """Long thin triangles (aspect 1:200) in random orientations inside a unit cube: many overlap along any line."""
-    g = np.random.Generator(np.random.Philox(key=key))
-    c = g.random((n, 3))
-    u = g.standard_normal((n, 3))
-    u /= np.linalg.norm(u, axis=1, keepdims=True)
-    v = np.cross(u, g.standard_normal((n, 3)))
-    v /= np.linalg.norm(v, axis=1, keepdims=True)
-    p = np.stack([c - u * 0.1, c + u * 0.1, c + v * 0.001], axis=1).reshape(-1, 3)
-    verts = np.zeros((3 * n, 8), dtype=np.float32)
-    verts[:, :3] = p
-    verts[:, 4] = 1.0
-    return verts, np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
-
+from scenes import skimming_rays as grazing, slivers
 
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 from test_oracle_golden import sphere5_mesh

@@ -69,7 +69,7 @@ def counter_roofs(c, sec=None, n_rays=None):
 
 
 def nearest(roofs):
-    best = max((k for k in roofs if "frac" in roofs[k]), key=lambda k: roofs[k]["frac"])
+    best = max((k for k in roofs if isinstance(roofs[k], dict) and "frac" in roofs[k]), key=lambda k: roofs[k]["frac"])
     return best, roofs[best]["frac"]
 
 
@@ -208,13 +208,12 @@ def refresh(line):
         old = line["roofline"]
         ref = old.get("reference_semantics_equiv", {})
         line["roofline"] = soup_1m_block(old["kernel_ms"], old.get("rays_per_launch", line["config"]["rays_per_gpu"]), old["culled_traversal"], ref.get("nodes_per_ray"), ref.get("tris_per_ray"))
+    n = line["config"]["rays_per_gpu"]
     for mesh, leg in (line.get("closest_10m") or {}).items():
-        for query in ("closest", "occlusion"):
-            key = "roofline" if query == "closest" else "roofline_occlusion"
-            old = leg.get(key)
-            if old:
-                ref = old.get("reference_semantics_equiv", {})
-                leg[key] = mesh_10m_block(mesh, query, old["kernel_ms"], old["rays_per_launch"], old.get("culled_traversal"), ref.get("nodes_per_ray"), ref.get("tris_per_ray"))
+        for query, key, ms_key in (("closest", "roofline", "closest_kernel_ms"), ("occlusion", "roofline_occlusion", "anyhit_kernel_ms")):
+            old = leg.get(key) or {}
+            ref = old.get("reference_semantics_equiv", {})
+            leg[key] = mesh_10m_block(mesh, query, old.get("kernel_ms", leg[ms_key]), old.get("rays_per_launch", n), old.get("culled_traversal"), ref.get("nodes_per_ray"), ref.get("tris_per_ray"))
     for r in line.get("renders", []):
         if r.get("leg") and r.get("traced_rays") is not None:
             ref = (r.get("roofline") or {}).get("reference_semantics")

@@ -1,6 +1,7 @@
 """Turns the rocprofv3 databases that tools/profile_gpu.sh left under gpurun_out/prof/ into the summaries kept under
 profiles/ for one round:  python tools/summarise_profiles.py r03
   rNN_kernel_stats_bench.csv   per-kernel time of the default bench command (kernel trace)
+  rNN_kernel_stats_bench_by_leg.json  the traversal kernels' launches of that trace split by the leg (mesh) they ran on
   rNN_bench_line.json          the line that command printed
   rNN_traffic.json             L2<->fabric bytes per launch of the culled closest-hit kernel (1M-triangle soup), L2 hit rate
   rNN_pmc_closest.json         per-launch counter sums of that kernel + derived busy fractions
@@ -133,6 +134,26 @@ if kernel_stats("trace", f"{RND}_kernel_stats_bench.csv"):
     lines = [l for l in open(os.path.join(G, "bench_under_rocprof.log")) if l.startswith("{")]
     if lines:
         json.dump(json.loads(lines[-1]), open(os.path.join(P, f"{RND}_bench_line.json"), "w"), indent=1)
+    # The command runs the culled closest-hit kernel on three meshes in turn (the 1M-triangle soup, then the two
+    # 10 M-triangle meshes), seconds apart (scene construction, CPU baselines): its launches split by the gaps.
+    c = db("trace")
+    by_leg = []
+    legs3 = ("config 3 (1M-triangle soup)", "cows10m", "soup10m")
+    rows = c.execute("select start, end from kernels where name like ? order by start", ("%" + CLOSEST + "%",)).fetchall()
+    windows = []     # a leg's window opens with its first closest-hit launch
+    for st, en in rows:
+        if not windows or st - last_end > 2.0e9:
+            windows.append(st)
+        last_end = en
+    for like, label in ((CLOSEST, "closest"), (ANYHIT, "occlusion")):
+        rows = c.execute("select start, end from kernels where name like ? order by start", ("%" + like + "%",)).fetchall()
+        for k, leg in enumerate(legs3[:len(windows)]):
+            lo, hi = windows[k], windows[k + 1] if k + 1 < len(windows) else float("inf")
+            d = [(en - st) / 1e6 for st, en in rows if lo <= st < hi]
+            if d:
+                by_leg.append({"kernel": like, "query": label, "leg": leg, "launches": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d)})
+    json.dump({**STAMP, "what": "launches of the culled closest-hit and occlusion kernels in the traced bench command, split by leg (a leg opens with the first closest-hit launch after a pause of more than 2 s: scene construction and ray generation lie between legs)",
+               "legs": by_leg}, open(os.path.join(P, f"{RND}_kernel_stats_bench_by_leg.json"), "w"), indent=1)
 
 # ---- culled closest-hit kernel, 1M-triangle soup
 cnt = {}
@@ -191,15 +212,6 @@ if pmc10:
     json.dump({**STAMP, "workload": "16777216 rays per launch, culled order", "command": cmd10,
                "note": "per-launch sums; derived fractions as in the 1M-triangle summary", "meshes": pmc10}, open(os.path.join(P, f"{RND}_pmc_closest_10m.json"), "w"), indent=1)
 
-# ---- the bench line's roofline blocks again, from the summaries just written (the run itself used the summaries
-# committed before it: same formulas, this run's counters), so that the line and the files beside it agree exactly
-line_path = os.path.join(P, f"{RND}_bench_line.json")
-if os.path.exists(line_path):
-    import bench
-    line = json.load(open(line_path))
-    bench.refresh_roofline_blocks(line)
-    json.dump(line, open(line_path, "w"), indent=1)
-
 # ---- render kernels
 kernel_stats("r_trace", f"{RND}_kernel_stats_render.csv")
 LEGS = {"cbox": (256, 16, "config 1: cbox.js3d 256x256, depth 4"), "refract_cow_cbox": (1024, 16, "config 2 / 4: refract_cow_cbox.js3d 1024x1024, depth 8"),
@@ -210,7 +222,7 @@ for leg, (w, spp, label) in LEGS.items():
     per_kernel = collections.defaultdict(dict)
     for d in ("sq1", "sq2", "mem", "fetch", "write", "l2"):
         for k, m in totals(f"r_{leg}_{d}").items():
-            if "rocclr" in k or "Cijk" in k:
+            if "rocclr" in k or "Cijk" in k or "k_gb_" in k or "(anonymous namespace)" in k:   # copies, library kernels, the tree builder (scene creation)
                 continue
             per_kernel[k].update(m)
     out = {}
@@ -236,3 +248,12 @@ if legs:
                "note": "sums over all dispatches of each kernel in one render (16 spp plus the driver's 1-spp warm-up); derived fractions as in the closest-hit summary; "
                        "fabric_bytes = (FETCH_SIZE + WRITE_SIZE) x 1024, taken as is (see the traffic summaries); fabric_bytes_per_path = sum over kernels / paths",
                "legs": legs}, open(os.path.join(P, f"{RND}_pmc_render.json"), "w"), indent=1)
+
+# ---- the bench line's roofline blocks again, from the summaries just written (the run itself used the summaries
+# committed before it: same formulas, this run's counters), so that the line and the files beside it agree exactly
+line_path = os.path.join(P, f"{RND}_bench_line.json")
+if os.path.exists(line_path):
+    import bench
+    line = json.load(open(line_path))
+    bench.refresh_roofline_blocks(line)
+    json.dump(line, open(line_path, "w"), indent=1)

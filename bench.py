@@ -353,7 +353,7 @@ def scene_query_leg(name, n, extent, dev, timed, steps):
            "anyhit_culled_mrays_per_s": round(n / any_ms / 1e3, 2), "anyhit_reference_mode_mrays_per_s": round(n / any_ref_ms / 1e3, 2),
            "culled_vs_reference_mode_mismatches": bad, "anyhit_culled_vs_reference_mismatches": int((occ_a != occ_b).sum().item()),
            "hit_fraction": round(float((a[:, 1] != -1).float().mean().item()), 4),
-           "kernels": {"culled": "k_scene_persistent (replenishing, phase-parked)", "reference": "k_trace_closest<reference order> (one ray per lane: exact by construction, the API default)"}}
+           "kernels": {"culled": "k_scene_persistent (replenishing, phase-parked)", "reference": "k_scene_persistent<reference order> (replenishing; every node and triangle the reference visits, in its order: exact by construction, the API default)"}}
     scene.close()
     return out
 

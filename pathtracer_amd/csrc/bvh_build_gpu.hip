@@ -318,21 +318,17 @@ __global__ void __launch_bounds__(256) k_gb_count(GNode* __restrict__ nodes, uin
 	else if (n_left != nl) atomicAdd(&c->disagreements, (unsigned long long)(n_left > nl ? n_left - nl : nl - n_left));
 }
 
-// Positions of the misplaced elements: the non-satisfying ones among the first n_left positions of the node's range
-// and the satisfying ones among the rest, each list in ascending position.
+// Positions of the satisfying elements behind the first n_left positions of the node's range, in ascending position
+// (their partners, the non-satisfying ones among the first n_left, find their rank from the prefix sums themselves).
 __global__ void __launch_bounds__(256) k_gb_positions(const uint32_t* __restrict__ node_of, uint32_t n, const GNode* __restrict__ nodes, uint32_t level_begin, const uint32_t* __restrict__ flag,
-                                                      const uint32_t* __restrict__ excl, uint32_t* __restrict__ fpos, uint32_t* __restrict__ bpos) {
+                                                      const uint32_t* __restrict__ excl, uint32_t* __restrict__ bpos) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t x = node_of[i];
 	if (x < level_begin || nodes[x].child == GB_NONE) return;
 	const GNode& node = nodes[x];
 	const uint32_t begin = node.start, j = i - begin, f = flag[i];
-	if (j < node.n_left) {
-		if (!f) fpos[begin + (j - (excl[i] - excl[begin]))] = i;
-	} else if (f) {
-		bpos[begin + (excl[i] - excl[begin + node.n_left])] = i;
-	}
+	if (j >= node.n_left && f) bpos[begin + (excl[i] - excl[begin + node.n_left])] = i;
 }
 
 // The exchanges, and which child every position of the range now belongs to.
@@ -392,6 +388,11 @@ struct DeviceBuffers {
 	~DeviceBuffers() {
 		for (void* p : all) (void)hipFree(p);
 	}
+	void release(void* p) {
+		if (!p) return;
+		all.erase(std::remove(all.begin(), all.end(), p), all.end());
+		(void)hipFree(p);
+	}
 	template<typename T>
 	hipError_t get(T** out, size_t count) {
 		void* p = nullptr;
@@ -421,7 +422,7 @@ int build_bvh_gpu(int device, const float* boxes, uint32_t n, uint32_t max_leaf_
 	DeviceBuffers mem;
 	float* d_boxes;
 	GPrim* prims;
-	uint32_t *node_of, *flag, *excl, *fpos, *bpos, *totals;
+	uint32_t *node_of, *flag, *excl, *bpos, *totals;
 	GNode* nodes;
 	GCounters* counters;
 	const uint64_t max_nodes = 2ull * n + 2;
@@ -430,7 +431,6 @@ int build_bvh_gpu(int device, const float* boxes, uint32_t n, uint32_t max_leaf_
 	PTX_HIP(mem.get(&node_of, n));
 	PTX_HIP(mem.get(&flag, n));
 	PTX_HIP(mem.get(&excl, size_t(n) + 1));
-	PTX_HIP(mem.get(&fpos, n));
 	PTX_HIP(mem.get(&bpos, n));
 	PTX_HIP(mem.get(&totals, blocks_for(n, SCAN_TILE)));
 	PTX_HIP(mem.get(&nodes, max_nodes));
@@ -456,8 +456,14 @@ int build_bvh_gpu(int device, const float* boxes, uint32_t n, uint32_t max_leaf_
 	size_t bins_capacity = 0;
 	for (;;) {
 		const uint32_t count = end - begin;
-		if (bins_capacity < count) {
-			bins_capacity = std::max<size_t>(count, bins_capacity * 2);
+		// One bin table (672 B) per node that will be split.  Such a node holds more than max_leaf primitives and the
+		// nodes of a level hold disjoint ranges, so a level never needs more than n / (max_leaf + 1) tables however many
+		// nodes it has; an outgrown array is freed before its successor is allocated.
+		const size_t need = std::min<size_t>(count, size_t(n) / (size_t(max_leaf_size) + 1) + 1);
+		if (bins_capacity < need) {
+			mem.release(bins);
+			bins = nullptr;
+			bins_capacity = std::min<size_t>(std::max<size_t>(need, bins_capacity * 2), size_t(n) / (size_t(max_leaf_size) + 1) + 1);
 			PTX_HIP(mem.get(&bins, bins_capacity));
 		}
 		PTX_HIP(hipMemsetAsync(&counters->n_active, 0, sizeof(uint32_t), st));
@@ -474,7 +480,7 @@ int build_bvh_gpu(int device, const float* boxes, uint32_t n, uint32_t max_leaf_
 		hipLaunchKernelGGL(k_gb_scan_totals, dim3(1), block, 0, st, totals, tiles, excl + n);
 		hipLaunchKernelGGL(k_gb_scan_add, grid_n, block, 0, st, excl, n, totals);
 		hipLaunchKernelGGL(k_gb_count, grid_level, block, 0, st, nodes, begin, end, excl, counters);
-		hipLaunchKernelGGL(k_gb_positions, grid_n, block, 0, st, node_of, n, nodes, begin, flag, excl, fpos, bpos);
+		hipLaunchKernelGGL(k_gb_positions, grid_n, block, 0, st, node_of, n, nodes, begin, flag, excl, bpos);
 		hipLaunchKernelGGL(k_gb_exchange, grid_n, block, 0, st, prims, node_of, n, nodes, begin, flag, excl, bpos);
 		begin = end, end = h.n_nodes;
 		level_begin.push_back(begin);

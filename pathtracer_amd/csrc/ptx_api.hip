@@ -1177,8 +1177,12 @@ static int trace_closest_resident(PtxScene* s, const PtxRay* d_rays, uint64_t n,
 	} else if (s->rec.mesh_only) {
 		if (culled) hipLaunchKernelGGL((k_trace_closest<MODE_CULLED, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
 		else hipLaunchKernelGGL((k_trace_closest<MODE_REFERENCE, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
-	} else if (culled && scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && n < (uint64_t(1) << 32)) {
-		if (int rc = launch_scene_persistent(s, BatchIO{d_rays, n, d_hits, d_bary, d_inst}, n)) return rc;
+	} else if (scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && n < (uint64_t(1) << 32)) {
+		if (culled) {
+			if (int rc = launch_scene_persistent(s, BatchIO{d_rays, n, d_hits, d_bary, d_inst}, n)) return rc;
+		} else {
+			if (int rc = (launch_scene_persistent<BatchIO, false, MODE_REFERENCE>(s, BatchIO{d_rays, n, d_hits, d_bary, d_inst}, n))) return rc;
+		}
 	} else {
 		if (culled) hipLaunchKernelGGL((k_trace_closest<MODE_CULLED, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
 		else hipLaunchKernelGGL((k_trace_closest<MODE_REFERENCE, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_hits, d_bary, d_inst);
@@ -1267,8 +1271,12 @@ static int trace_any_resident(PtxScene* s, const PtxRay* d_rays, uint64_t n, uin
 	} else if (s->rec.mesh_only) {
 		if (culled) hipLaunchKernelGGL((k_trace_any<MODE_CULLED, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
 		else hipLaunchKernelGGL((k_trace_any<MODE_REFERENCE, true>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
-	} else if (culled && scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && n < (uint64_t(1) << 32)) {
-		if (int rc = (launch_scene_persistent<BatchAnyIO, true>(s, BatchAnyIO{d_rays, n, d_occ}, n))) return rc;
+	} else if (scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && n < (uint64_t(1) << 32)) {
+		if (culled) {
+			if (int rc = (launch_scene_persistent<BatchAnyIO, true>(s, BatchAnyIO{d_rays, n, d_occ}, n))) return rc;
+		} else {
+			if (int rc = (launch_scene_persistent<BatchAnyIO, true, MODE_REFERENCE>(s, BatchAnyIO{d_rays, n, d_occ}, n))) return rc;
+		}
 	} else {
 		if (culled) hipLaunchKernelGGL((k_trace_any<MODE_CULLED, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);
 		else hipLaunchKernelGGL((k_trace_any<MODE_REFERENCE, false>), grid, block, 0, s->stream, s->rec, d_rays, n, d_occ);

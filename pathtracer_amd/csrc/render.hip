@@ -750,6 +750,7 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 		ShadeTables shade_tables = s->shade;
 		if (trace_unused) shade_tables.direct_skip = 0;
 		const bool persistent = scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && !reference_order && np >= (1u << 18);
+		const bool persistent_reference = scene_persistent_ok(s) && !(flags & PTX_NO_PERSISTENT) && reference_order && np >= (1u << 18);
 		for (uint32_t k = 0; k < max_samples; k += group) {
 			PTX_HIP(hipMemsetAsync(rb.counts, 0, 256, s->stream));
 			hipLaunchKernelGGL(k_raygen, dim3((np + RAYGEN_BLOCK - 1) / RAYGEN_BLOCK), dim3(RAYGEN_BLOCK), 0, s->stream, rb, k, cr, key0, key1, rb.active[0], rb.counts + 0);
@@ -764,6 +765,8 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 				const RenderIO io{rb, rb.active[cur], rb.counts + cur, (last_vertex_round && !trace_unused) ? 0u : 1u};
 				if (persistent) {
 					if (int rc = launch_scene_persistent(s, io, 2 * n_paths)) return rc;
+				} else if (persistent_reference) {
+					if (int rc = (launch_scene_persistent<RenderIO, false, MODE_REFERENCE>(s, io, 2 * n_paths))) return rc;
 				} else if (reference_order) {
 					hipLaunchKernelGGL(k_extend<MODE_REFERENCE>, grid_items, block, 0, s->stream, s->rec, io);
 				} else {
@@ -781,6 +784,8 @@ extern "C" int ptx_render_tiles(ptx_scene_t s, const PtxCamera* cam, const PtxTi
 					const uint64_t max_items = n_paths * n_lights;
 					if (persistent) {
 						if (int rc = (launch_scene_persistent<ShadowIO, true>(s, sio, max_items))) return rc;
+					} else if (persistent_reference) {
+						if (int rc = (launch_scene_persistent<ShadowIO, true, MODE_REFERENCE>(s, sio, max_items))) return rc;
 					} else {
 						const dim3 grid_shadow(uint32_t((max_items + 255) / 256));
 						if (reference_order) hipLaunchKernelGGL(k_shadow_plain<MODE_REFERENCE>, grid_shadow, block, 0, s->stream, s->rec, sio);

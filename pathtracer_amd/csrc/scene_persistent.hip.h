@@ -107,10 +107,14 @@ struct ListIO {
 // ZERO: the second pass, over the rays the first one set aside: world or object-space rays with direction components
 // that are exactly zero are walked with the zero-aware slab tests of traverse.hip.h (a kernel of its own, so the
 // first pass carries none of that code).
-template<typename IO, bool ANY = false, bool ZERO = false>
+// MODE: MODE_CULLED as described above.  MODE_REFERENCE is the reference's own walk -- every node
+// whose ancestors pass the box test, left before right, nothing skipped for distance (bvh.cpp:272-375), Trace::min
+// folded in array order at both levels (trace.h:28-36) -- in the same lane machine: a lane that reaches a triangle
+// leaf does not walk on (no parking: its next step depends on that leaf's fold), it waits for the wave's next
+// triangle phase and pops afterwards.
+template<typename IO, bool ANY = false, bool ZERO = false, int MODE = MODE_CULLED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_scene_persistent(SceneRec sc, IO io, unsigned long long* __restrict__ next_item, uint32_t* __restrict__ slow_list,
                                                           uint32_t* __restrict__ slow_count, const int refill_min, const unsigned long long wave_chunk, const int walk_steps) {
-	constexpr int MODE = MODE_CULLED;
 	const unsigned lane = threadIdx.x & 63u;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
 	const uint64_t n_items = io.count();
@@ -169,11 +173,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 			settle_top();
 		}
 	};
-	// Trace::min at the Aggregate level with the order-free tie rule (larger instance index wins a tie).
+	// Trace::min at the Aggregate level: in the reference order as it stands (the candidate replaces the running hit
+	// unless that is strictly closer: instances are folded in array order), in the culled order with the order-free
+	// tie rule (larger instance index wins a tie).
 	auto fold_world = [&](uint32_t inst, bool hit, float dist, float t, uint32_t prim, float u, float v) {
 		if (hit) {
-			bool keep = best_hit && !(dist < best_distance);
-			if (keep && dist == best_distance) keep = !(inst > ledger[L_INST]);
+			bool keep = MODE == MODE_REFERENCE ? (best_hit && best_distance < dist) : (best_hit && !(dist < best_distance));
+			if (MODE != MODE_REFERENCE && keep && dist == best_distance) keep = !(inst > ledger[L_INST]);
 			if (!keep) {
 				best_hit = true, best_distance = dist;
 				ledger[L_T] = __float_as_uint(t), ledger[L_PRIM] = prim, ledger[L_INST] = inst, ledger[L_U] = __float_as_uint(u), ledger[L_V] = __float_as_uint(v);
@@ -254,12 +260,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 		// as one issued for all 64), so each phase's code runs with as many lanes as the wave can muster.
 		// a lane standing on a triangle leaf with its parking slot free parks it and takes its next
 		// pending subtree (empty leaves are dropped on the way)
-		while (have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE && pend == 0u) {
+		// (culled order only: in the reference order the lane stays on its leaf until the triangle phase has folded it)
+		while (MODE == MODE_CULLED && have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE && pend == 0u) {
 			if (ref & 15u) pend = ref;
 			pop_ref<MODE, ANY>(cr, st, base, sp, ref, mh.hit, mh.distance);
 		}
 		const bool can_walk = have_ray && !(ref & REF_LEAF);
-		const bool has_parked = have_ray && pend != 0u;
+		const bool has_parked = MODE == MODE_CULLED ? (have_ray && pend != 0u) : (have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE);
 		const bool want_enter = have_ray && level == 0u && (ref & REF_LEAF) && ref != REF_DONE;
 		const bool want_exit = have_ray && level == 1u && ref == REF_DONE && pend == 0u;
 		const int n_walk = __popcll(__ballot(can_walk)), n_tri = __popcll(__ballot(has_parked));
@@ -283,7 +290,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 				if (have_ray && !(ref & REF_LEAF)) {
 					const bool run_hit = level ? mh.hit : best_hit;
 					const float run_dist = level ? mh.distance : best_distance;
-					node_step<MODE, ANY, true, false, ZERO>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
+					// (both orders decide with the approximate slab test, exact where it cannot tell: only the decisions matter)
+					node_step<MODE, ANY, true, false, ZERO, true>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
 					if (level == 0u) settle_top();
 				}
 			}
@@ -293,9 +301,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 			prof[3]++, prof[4] += n_tri;
 #endif
 			if (has_parked) {
-				mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (pend & REF_INDEX_MASK) >> 4, pend & 15u, cr, mh, nullptr);
-				pend = 0u;
-				if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
+				if (MODE == MODE_CULLED) {
+					mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (pend & REF_INDEX_MASK) >> 4, pend & 15u, cr, mh, nullptr);
+					pend = 0u;
+					if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
+				} else {
+					mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (ref & REF_INDEX_MASK) >> 4, ref & 15u, cr, mh, nullptr);
+					if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
+					else pop_ref<MODE, ANY>(cr, st, base, sp, ref, mh.hit, mh.distance);
+				}
 			}
 		} else if (n_exit == n_max) {
 			// ---- leave an instance: Instance::hit's tail (instance.h:36-39): Trace::transform(T, iT.T())
@@ -376,7 +390,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 }
 
 // The rays k_scene_persistent set aside: one ray per lane, plain divisions, any scene.
-template<typename IO, bool ANY = false>
+template<typename IO, bool ANY = false, int MODE = MODE_CULLED>
 __global__ void __launch_bounds__(256) k_scene_deferred(SceneRec sc, IO io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count) {
 	const uint32_t n = *count;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
@@ -385,8 +399,8 @@ __global__ void __launch_bounds__(256) k_scene_deferred(SceneRec sc, IO io, cons
 		io.load(out, r);
 		Stack st;
 		SceneHit h;
-		traverse_scene<MODE_CULLED, ANY>(sc, r, st, h);
-		if (!ANY && needs_reference_order(r, h.hit, h.distance)) traverse_scene<MODE_REFERENCE, false>(sc, r, st, h);
+		traverse_scene<MODE, ANY>(sc, r, st, h);
+		if (MODE == MODE_CULLED && !ANY && needs_reference_order(r, h.hit, h.distance)) traverse_scene<MODE_REFERENCE, false>(sc, r, st, h);
 		io.store(out, h);
 	}
 }
@@ -396,7 +410,7 @@ __global__ void __launch_bounds__(256) k_scene_deferred(SceneRec sc, IO io, cons
 // exactly (lists, untamed trees) send their rays to k_scene_deferred one by one.
 inline bool scene_persistent_ok(const PtxScene* s) { return !s->rec.mesh_only && !s->rec.top_is_list && s->rec.top_tame && s->rec.n_insts > 0; }
 
-template<typename IO, bool ANY = false>
+template<typename IO, bool ANY = false, int MODE = MODE_CULLED>
 int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 	unsigned long long* counters = nullptr;
 	if (int rc = scene_counter_block(s, &counters)) return rc;
@@ -412,7 +426,7 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 	static const int walk_steps = getenv("PTX_SCENE_WALK_STEPS") ? std::max(1, atoi(getenv("PTX_SCENE_WALK_STEPS"))) : SCENE_WALK_STEPS;
 	const uint64_t want = (max_items + 255) / 256;
 	const dim3 block(256), grid(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(s->cu_count) * uint64_t(std::max(1, blocks_per_cu))))));
-	hipLaunchKernelGGL((k_scene_persistent<IO, ANY>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count, refill_min, wave_chunk, walk_steps);
+	hipLaunchKernelGGL((k_scene_persistent<IO, ANY, false, MODE>), grid, block, 0, s->stream, s->rec, io, counters, slow_list, slow_count, refill_min, wave_chunk, walk_steps);
 #ifdef PTX_PROFILE_LANES
 	{
 		static unsigned long long tot[9] = {};
@@ -434,8 +448,8 @@ int launch_scene_persistent(PtxScene* s, const IO& io, uint64_t max_items) {
 	uint32_t* slow_list2 = static_cast<uint32_t*>(s->scratch[8]);
 	unsigned long long* counters2 = counters + 128;   // the second half of the counter block
 	uint32_t* slow_count2 = reinterpret_cast<uint32_t*>(counters2) + 16;
-	hipLaunchKernelGGL((k_scene_persistent<ListIO<IO>, ANY, true>), grid, block, 0, s->stream, s->rec, ListIO<IO>{io, slow_list, slow_count}, counters2, slow_list2, slow_count2, refill_min, wave_chunk, walk_steps);
-	hipLaunchKernelGGL((k_scene_deferred<IO, ANY>), dim3(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, 256)))), block, 0, s->stream, s->rec, io, slow_list2, slow_count2);
+	hipLaunchKernelGGL((k_scene_persistent<ListIO<IO>, ANY, true, MODE>), grid, block, 0, s->stream, s->rec, ListIO<IO>{io, slow_list, slow_count}, counters2, slow_list2, slow_count2, refill_min, wave_chunk, walk_steps);
+	hipLaunchKernelGGL((k_scene_deferred<IO, ANY, MODE>), dim3(uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(want, 256)))), block, 0, s->stream, s->rec, io, slow_list2, slow_count2);
 	return PTX_OK;
 }
 

@@ -408,8 +408,14 @@ __device__ __forceinline__ void node4_decide(const Node4* __restrict__ node, con
 // The four 16-byte pieces of a node record, requested back to back and waited for TOGETHER.  Left to the compiler
 // the loads are followed by one wait per piece with the first arithmetic in between (a wave that wakes up four
 // times per node): measured on the 1M-triangle soup that form walks 16.7 M rays in 13.3 ms, this one in 11.8 ms.
+// The block below is gfx9-family assembly (global_load_dwordx4 ... off, ds_read_b128, s_waitcnt vmcnt / lgkmcnt): it is
+// the default on those targets only; any other target (and the host pass) takes the plain C++ form.
 #ifndef PTX_NODE_FETCH
+#if defined(__gfx950__) || defined(__gfx942__) || defined(__gfx940__) || defined(__gfx941__) || defined(__gfx90a__) || defined(__gfx908__) || defined(__gfx906__) || defined(__gfx900__)
 #define PTX_NODE_FETCH 1
+#else
+#define PTX_NODE_FETCH 0
+#endif
 #endif
 __device__ __forceinline__ void fetch_node(const Node2* __restrict__ node, float4& n0, float4& n1, float4& n2, uint2& kids) {
 #if PTX_NODE_FETCH

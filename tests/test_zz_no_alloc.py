@@ -34,6 +34,44 @@ def _rays(n, key):
     return rays
 
 
+def test_noalloc_allocates_nothing():
+    """The entry point's defining property: on a scene that no allocating call has touched (so none of the scene's
+    grown-on-demand buffers exist), free device memory is the same before and after every call, at the largest size, a
+    grouped smaller one and one below the grouping threshold, synchronous and PTX_ASYNC; only afterwards does the
+    allocating entry point run on the same scene, and its answers are the same."""
+    import torch
+    dev = torch.device("cuda", 0)
+    verts, idx = synth.soup(150000, key=77)
+    scene = capi.Scene.from_mesh(verts, idx)
+    scene.set_stream(torch.cuda.current_stream().cuda_stream)
+    sizes = (1 << 20, 70001, 1000)
+    batches = [_rays(n, key=950 + k) for k, n in enumerate(sizes)]
+    rays = [torch.from_numpy(r.view(np.float32).reshape(-1, 8).copy()).to(dev) for r in batches]
+    hits = [torch.zeros((n, 2), dtype=torch.int32, device=dev) for n in sizes]
+    bary = [torch.zeros((n, 2), dtype=torch.float32, device=dev) for n in sizes]
+    inst = [torch.zeros((n,), dtype=torch.int32, device=dev) for n in sizes]
+    want = [(torch.zeros_like(h), torch.zeros_like(b), torch.zeros_like(i)) for h, b, i in zip(hits, bary, inst)]
+    # code objects load on a kernel's first launch: one call per mode before measuring
+    for flags in (abi.PTX_TRAVERSE_CULLED, abi.PTX_TRAVERSE_REFERENCE):
+        scene.trace_closest_noalloc(rays[0], hits[0], bary[0], inst[0], flags=flags | abi.PTX_MEM_DEVICE, n=sizes[0])
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for flags in (abi.PTX_TRAVERSE_CULLED, abi.PTX_TRAVERSE_REFERENCE, abi.PTX_TRAVERSE_CULLED | abi.PTX_RAYS_COHERENT, abi.PTX_TRAVERSE_CULLED | abi.PTX_ASYNC):
+        for k, n in enumerate(sizes):
+            scene.trace_closest_noalloc(rays[k], hits[k], bary[k], inst[k], flags=flags | abi.PTX_MEM_DEVICE, n=n)
+            if flags & abi.PTX_ASYNC:
+                torch.cuda.current_stream().synchronize()
+            assert torch.cuda.mem_get_info(0)[0] == free0, f"flags={flags} n={n}: free device memory changed across an allocation-free call"
+    torch.cuda.synchronize()
+    for k, n in enumerate(sizes):       # now the allocating entry point, for the comparison
+        scene.trace_closest_device(rays[k], want[k][0], want[k][1], want[k][2], flags=abi.PTX_TRAVERSE_CULLED, n=n)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] < free0        # ... which does grow the scene's buffers
+    for k in range(len(sizes)):
+        assert torch.equal(hits[k], want[k][0]) and torch.equal(bary[k].view(torch.int32), want[k][1].view(torch.int32)) and torch.equal(inst[k], want[k][2])
+    scene.close()
+
+
 def test_noalloc_equals_allocating_entry_point_on_calls_in_a_row():
     verts, idx = synth.soup(200000)
     scene = capi.Scene.from_mesh(verts, idx)

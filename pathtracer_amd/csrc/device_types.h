@@ -117,7 +117,7 @@ struct SceneRec {
 	uint32_t mesh_only;       // queries go straight to meshes[0] (PT::Tri_Mesh::hit)
 	uint32_t top_tame;        // as MeshRec::tame, for the top-level tree
 	uint32_t top_stack_slots; // stack slots reserved for the top-level traversal
-	uint32_t pad;
+	uint32_t lds_mesh;        // the mesh most instances refer to (experiment switch PTX_SCENE_TOP_LDS)
 };
 
 // Hit record passed from the extend stage to the shade stage (two 16-byte stores).

@@ -947,6 +947,15 @@ int ptx_scene_create(int device, const PtxSceneDesc* d, ptx_scene_t* out) {
 		for (uint32_t i = 0; i < d->n_instances; i++) s->top_bvh.order[i] = i;
 	}
 	for (uint32_t i = 0; i < d->n_instances; i++) insts[i] = insts_in[s->top_bvh.order[i]];
+	{   // the mesh most instances refer to (ties: the larger one)
+		std::vector<uint32_t> uses(d->n_meshes, 0u);
+		for (const InstRec& r : insts)
+			if (r.mesh >= 0) uses[size_t(r.mesh)]++;
+		uint32_t best = 0;
+		for (uint32_t m = 1; m < d->n_meshes; m++)
+			if (uses[m] > uses[best] || (uses[m] == uses[best] && d->meshes[m].n_tris > d->meshes[best].n_tris)) best = m;
+		s->rec.lds_mesh = best;
+	}
 	s->stack_need = s->top_bvh.max_depth + deepest_mesh + 3;
 	if (s->stack_need > uint32_t(STACK_CAP)) return bail(fail(PTX_ERR_UNSUPPORTED, "trees deeper than the traversal stack (64 entries)"));
 

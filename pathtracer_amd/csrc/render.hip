@@ -197,6 +197,10 @@ constexpr int RAYGEN_BLOCK = 1024;
 #define PTX_SHADE_BLOCK 512
 #endif
 constexpr int SHADE_BLOCK = PTX_SHADE_BLOCK;
+#ifndef PTX_SHADE_SORT
+#define PTX_SHADE_SORT 0
+#endif
+static_assert(!PTX_SHADE_SORT || (SHADE_BLOCK / 64) * 8 <= 64, "the slot table of the in-block regrouping is scanned by one wave");
 
 // Camera::sample_ray for samples k0 .. k0 + group - 1 of every slot that has them (pathtracer.cpp:448-454).
 __global__ void __launch_bounds__(RAYGEN_BLOCK) k_raygen(RenderBuffers rb, uint32_t k0, CameraRec cam, uint32_t key0, uint32_t key1,
@@ -353,9 +357,63 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables 
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	bool alive = false, wants_direct = false;
 	uint32_t path = 0;
-	if (i < *count) {
+	bool have_path = i < *count;
+	if (have_path) path = list[i];
+#if PTX_SHADE_SORT
+	// The block's paths regrouped by what their vertex will cost, before any of it is computed: paths whose vertex
+	// scatters (surface rebuilt, two BSDF samples, the emitter pre-test) first, one material kind after the other, then
+	// the cheap ones (missed, met a lamp, last vertex).  A wave then holds paths of one kind and its instructions run
+	// with all lanes; which thread shades which path changes nothing in what is computed for it.
+	{
+		constexpr int WAVES = SHADE_BLOCK / 64, KEYS = 8;
+		__shared__ uint32_t s_path[SHADE_BLOCK];
+		__shared__ uint32_t s_slot[WAVES * KEYS];
+		const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+		uint32_t key = KEYS - 1;   // no path
+		if (have_path) {
+			const uint32_t word = __float_as_uint(rb.state[path].w);
+			const uint2 hb = rb.hit_b[0][path];
+			key = 5;               // cheap: nothing scatters
+#if PTX_SHADE_SORT == 2
+			// variant: by the instance the main ray hit, in seven runs of the (spatially ordered) instance array, so that
+			// the rays leaving one part of the scene are neighbours in the next extend round
+			key = hb.x != 0xFFFFFFFFu ? min(6u, uint32_t((uint64_t(hb.y) * 7u) / max(sc.n_insts, 1u))) : 6u;
+			if (false)
+#endif
+			if (((word & PATH_CAMERA) || path_depth(word) != 0) && hb.x != 0xFFFFFFFFu && path_depth(word) != 0) {
+				const int32_t mat_id = sc.insts[hb.y].material;
+				if (mat_id >= 0) {
+					const uint32_t type = sh.materials[mat_id].type;
+					if (type != PTX_MAT_EMISSIVE) key = type;   // 0 Lambertian, 1 Mirror, 2 Refract, 3 Glass
+				}
+			}
+		}
+		uint32_t rank = 0;
+		for (uint32_t k = 0; k < KEYS; k++) {
+			const unsigned long long m = __ballot(key == k);
+			if (lane == 0) s_slot[k * WAVES + wave] = uint32_t(__popcll(m));
+			if (key == k) rank = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+		}
+		__syncthreads();
+		if (threadIdx.x < 64) {   // exclusive prefix over (key, wave), key-major
+			const uint32_t c = lane < WAVES * KEYS ? s_slot[lane] : 0u;
+			uint32_t incl = c;
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint32_t o = __shfl_up(incl, d);
+				if (int(lane) >= d) incl += o;
+			}
+			if (lane < WAVES * KEYS) s_slot[lane] = incl - c;
+		}
+		__syncthreads();
+		s_path[s_slot[key * WAVES + wave] + rank] = have_path ? path : 0xFFFFFFFFu;
+		__syncthreads();
+		path = s_path[threadIdx.x];
+		have_path = path != 0xFFFFFFFFu;
+		if (!have_path) path = 0;
+	}
+#endif
+	if (have_path) {
 		SHADE_SITE(0);
-		path = list[i];
 		const float4 st = rb.state[path];
 		V3f T = v3(st.x, st.y, st.z);
 		const uint32_t word = __float_as_uint(st.w);

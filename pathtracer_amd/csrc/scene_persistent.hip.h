@@ -34,6 +34,14 @@ constexpr unsigned long long SCENE_WAVE_CHUNK = 128;
 constexpr int SCENE_WALK_STEPS = 6;   // box steps per WALK phase
 constexpr int SCENE_REFILL_MIN_IDLE = 8;
 constexpr uint32_t SCENE_ITERATION_CAP = 1u << 24;   // per wave; ordinary launches stay below 2^20
+// Experiment switches (measured, see the design notes): the first PTX_SCENE_TOP_LDS node records of one tree are kept
+// in LDS -- the instance-level tree's (PTX_SCENE_TOP_LDS_LEVEL 0) or those of the mesh most instances refer to (1).
+#ifndef PTX_SCENE_TOP_LDS
+#define PTX_SCENE_TOP_LDS 0
+#endif
+#ifndef PTX_SCENE_TOP_LDS_LEVEL
+#define PTX_SCENE_TOP_LDS_LEVEL 0
+#endif
 
 // Where rays come from and where hits go.  fetch() returns false for an item that carries no ray.
 struct BatchIO {   // ptx_trace_closest on a general scene
@@ -120,6 +128,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 	const uint64_t n_items = io.count();
 	if (ZERO && n_items == 0) return;   // nothing was set aside: the usual case
 
+	constexpr int STOP = (MODE == MODE_CULLED && !ZERO) ? PTX_SCENE_TOP_LDS : 0;
+	__shared__ float4 lds_tree_top[STOP > 0 ? STOP * 4 : 1];
+	const uint32_t lds_tree_base = PTX_SCENE_TOP_LDS_LEVEL ? sc.meshes[sc.lds_mesh].node_base : sc.top_node_base;
+	if (STOP > 0) {
+		// the node array is padded by 128 records on the host, so this read stays inside it for any tree
+		for (int i = threadIdx.x; i < STOP * 4; i += 256) lds_tree_top[i] = reinterpret_cast<const float4*>(sc.nodes + lds_tree_base)[i];
+		__syncthreads();
+	}
 	__shared__ uint32_t lds_ref[SCENE_LDS_SLOTS * 256];
 	__shared__ float lds_tnear[SCENE_LDS_SLOTS * 256];
 	Stack spill;
@@ -291,7 +307,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 					const bool run_hit = level ? mh.hit : best_hit;
 					const float run_dist = level ? mh.distance : best_distance;
 					// (both orders decide with the approximate slab test, exact where it cannot tell: only the decisions matter)
-					node_step<MODE, ANY, true, false, ZERO, true>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
+					if (STOP > 0) {
+						float4 n0, n1, n2;
+						uint2 kids;
+						const uint32_t index = ref & REF_INDEX_MASK;
+						if (cnode_base == lds_tree_base && index < uint32_t(STOP)) fetch_node_lds(lds_tree_top, index, n0, n1, n2, kids);
+						else fetch_node(sc.nodes + cnode_base + index, n0, n1, n2, kids);
+						node_decide<MODE, ANY, true, false, ZERO, true>(n0, n1, n2, kids, cr, cinv, st, base, sp, ref, run_hit, run_dist);
+					} else {
+						node_step<MODE, ANY, true, false, ZERO, true>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
+					}
 					if (level == 0u) settle_top();
 				}
 			}

@@ -1,0 +1,82 @@
+"""Measured-and-dropped tuning experiments of one round, from the A/B timing logs (tools/ab_render.sh) and the counter
+passes (tools/profile_experiments.sh):  python tools/summarise_experiments.py r03 > profiles/r03_scene_experiments.json
+Per variant: best render time per configuration against the shipped library in the same run, and for the two kernels
+that make up a render (extend: k_scene_persistent<RenderIO>, shade: k_shade) the vector-ALU busy fraction, the lanes
+active per vector instruction and the instructions issued, over a 16 spp render of configs 2 and 5."""
+import glob
+import json
+import os
+import re
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+CUS = 256
+EXPERIMENTS = {
+    "shadesort": {"log": "ab_shadesort.log", "flag": "-DPTX_SHADE_SORT=1",
+                  "what": "k_shade regroups its block's 512 paths in LDS before shading them: scattering vertices first, one material kind after the other, then the cheap "
+                          "paths (missed, met a lamp, last vertex) -- a stable counting sort on 8 keys (ballots, one prefix over waves x keys, one LDS exchange), no extra pass over "
+                          "the path list; the survivors' list inherits the grouping (rays leaving surfaces of one kind are neighbours in the next extend round)"},
+    "instsort": {"log": "ab_instsort.log", "flag": "-DPTX_SHADE_SORT=2",
+                 "what": "the same in-block regrouping keyed by the instance the path's main ray hit (seven runs of the spatially ordered instance array, misses last): "
+                         "rays leaving one part of the scene become neighbours in the survivors' list, hence in the next extend round"},
+    "toplds0": {"log": "ab_toplds.log", "flag": "-DPTX_SCENE_TOP_LDS=16 -DPTX_SCENE_TOP_LDS_LEVEL=0",
+                "what": "k_scene_persistent keeps the first 16 node records (breadth-first) of the instance-level tree in LDS (1 KB: what five 31 KB blocks per CU leave free)"},
+    "toplds1": {"log": "ab_toplds.log", "flag": "-DPTX_SCENE_TOP_LDS=16 -DPTX_SCENE_TOP_LDS_LEVEL=1",
+                "what": "the same 1 KB holds the first 16 node records of the mesh most instances refer to (the cow)"},
+}
+
+
+def ab_times(log):
+    """{variant: {config: best seconds}} from an ab_render.sh log."""
+    out, cur = {}, None
+    for line in open(os.path.join(G, log)):
+        m = re.match(r"== (\S+)", line)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.match(r"config (\S+): .*?: ([0-9.]+) s, .* checksum (\d+)", line)
+        if m and cur:
+            e = out.setdefault(cur, {}).setdefault(m.group(1), {"s": 1e9, "checksum": m.group(3)})
+            e["s"] = min(e["s"], float(m.group(2)))
+    return out
+
+
+def kernel_counters(variant, leg):
+    f = glob.glob(os.path.join(G, "prof_exp", f"{variant}_{leg}", "**", "*.db"), recursive=True)
+    if not f:
+        return {}
+    c = sqlite3.connect(f[0])
+    agg = {}
+    for k, n, v in c.execute("select kernel_name, counter_name, sum(value) from counters_collection group by kernel_name, counter_name"):
+        agg.setdefault(k, {})[n] = v
+    out = {}
+    for name, label in (("k_scene_persistent<ptx::RenderIO, false, false", "extend"), ("k_shade<", "shade")):
+        for k, m in agg.items():
+            if name in k and "GRBM_GUI_ACTIVE" in m:
+                cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+                out[label] = {"gpu_cycles_per_xcd": cyc, "valu_busy": round(4.0 * m["SQ_ACTIVE_INST_VALU"] / (cyc * CUS * 4), 4),
+                              "lanes_per_valu_instruction": round(m["SQ_THREAD_CYCLES_VALU"] / m["SQ_INSTS_VALU"], 2), "valu_instructions": m["SQ_INSTS_VALU"], "waves": m["SQ_WAVES"]}
+    return out
+
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+result = {"round": rnd, "method": "tools/build_variant.sh NAME FLAGS; tools/ab_render.sh NAME (shipped and variant alternating on one box, best of 3 renders, twice); tools/profile_experiments.sh NAME "
+                                  "(rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/prof_render.py 16 <leg>)",
+          "configs": {"2": "refract_cow_cbox 1024x1024 256 spp depth 8", "5": "1,728 instanced cows 1024x1024 64 spp depth 8", "5f": "the same cows as one 10.1 M-triangle mesh, 1024x1024 64 spp depth 8"},
+          "experiments": []}
+for name, e in EXPERIMENTS.items():
+    t = ab_times(e["log"])
+    entry = {"name": name, "build_flags": e["flag"], "what": e["what"], "render_seconds": {}, "bit_identical_accumulator": True, "counters_16spp": {}}
+    for cfg, ship in t.get("shipped", {}).items():
+        var = t.get(name, {}).get(cfg)
+        if var:
+            entry["render_seconds"][cfg] = {"shipped": ship["s"], "variant": var["s"], "change_percent": round(100.0 * (var["s"] / ship["s"] - 1.0), 1)}
+            entry["bit_identical_accumulator"] &= var["checksum"] == ship["checksum"]
+    for leg, cfg in (("refract_cow_cbox", "2"), ("instanced_cows", "5")):
+        entry["counters_16spp"][cfg] = {"shipped": kernel_counters("shipped", leg), "variant": kernel_counters(name, leg)}
+    worse = [v["change_percent"] for v in entry["render_seconds"].values()]
+    entry["outcome"] = f"dropped: {min(worse):+.1f} % to {max(worse):+.1f} % render time" if worse and min(worse) > 0 else "see numbers"
+    result["experiments"].append(entry)
+print(json.dumps(result, indent=1))

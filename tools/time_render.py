@@ -1,5 +1,5 @@
 """Timing driver for the render legs (device-resident accumulator, best of N):
-   python3 tools/time_render.py [config ...]      config: 2 (refract_cow_cbox 1024^2 x 256 spp), 5 (12^3 cows 1024^2 x 64 spp),
+   python3 tools/time_render.py [config ...]      config: 2 (refract_cow_cbox 1024^2 x 256 spp), 5 (12^3 cows 1024^2 x 64 spp), 5f (the same cows as one flattened mesh),
                                                   1 (cbox 256^2 x 16 spp), d (delta-lit test room 1024^2 x 64 spp)
 Prints seconds per render and the accumulator's checksum (equal across library variants: PTX_AMD_LIB=...)."""
 import os
@@ -41,6 +41,7 @@ CONFIGS = {
     "2c": ("refract_cow_cbox 4096x4096 16 spp depth 8", lambda: fixture("refract_cow_cbox"), 4096, 16, 8),
     "2d": ("refract_cow_cbox 512x512 1024 spp depth 8", lambda: fixture("refract_cow_cbox"), 512, 1024, 8),
     "5": ("12^3 instanced cows 1024x1024 64 spp depth 8", lambda: scenes.instanced_cows(12), 1024, 64, 8),
+    "5f": ("12^3 cows baked into one 10.1 M-triangle mesh 1024x1024 64 spp depth 8", lambda: scenes.flattened_cow_scene(12), 1024, 64, 8),
     "d": ("delta-lit room 1024x1024 64 spp depth 4", delta_room, 1024, 64, 4),
 }
 reps = int(os.environ.get("REPS", "3"))

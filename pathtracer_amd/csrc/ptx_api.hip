@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <random>
 #include <string>
@@ -121,8 +122,25 @@ __global__ void __launch_bounds__(256) k_selftest_division(uint64_t pairs_per_th
 }
 
 // ------------------------------------------------------------------ flattening
+// Arrays of hundreds of megabytes whose every element is written by a parallel pass right after allocation: a
+// vector that value-initialises them first would spend as long again clearing them on one thread.
+template<typename T>
+struct NoInitAlloc : std::allocator<T> {
+	template<typename U>
+	struct rebind {
+		using other = NoInitAlloc<U>;
+	};
+	template<typename U, typename... Args>
+	void construct(U* p, Args&&... args) {
+		if constexpr (sizeof...(Args) == 0) ::new (static_cast<void*>(p)) U;
+		else ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+	}
+};
+template<typename T>
+using BigVector = std::vector<T, NoInitAlloc<T>>;
+
 struct FlatTree {
-	std::vector<Node2> nodes;
+	BigVector<Node2> nodes;
 	uint32_t root_ref = make_leaf_ref(0, 0);
 	uint32_t depth = 0;
 	uint32_t n_nocull = 0;   // child references marked REF_NOCULL
@@ -138,48 +156,126 @@ static bool tame_coord_host(float c) {
 	return e >= uint32_t(127 - 70) && e <= uint32_t(127 + 38);
 }
 
+// Runs fn(task) for task = 0 .. n_tasks-1 on the builder's worker threads, tasks handed out one at a time (they are
+// subtrees of very different sizes).
+static void parallel_tasks(size_t n_tasks, uint64_t work, const std::function<void(size_t)>& fn) {
+	const unsigned threads = work >= (1u << 17) ? std::min<unsigned>(build_threads(), unsigned(std::max<size_t>(1, n_tasks))) : 1u;
+	if (threads <= 1) {
+		for (size_t t = 0; t < n_tasks; t++) fn(t);
+		return;
+	}
+	std::atomic<size_t> next{0};
+	auto run = [&] {
+		for (size_t t = next.fetch_add(1); t < n_tasks; t = next.fetch_add(1)) fn(t);
+	};
+	std::vector<std::thread> pool;
+	for (unsigned k = 1; k < threads; k++) pool.emplace_back(run);
+	run();
+	for (auto& t : pool) t.join();
+}
+
 // Canonical node array -> interior-only Node2 array (children's boxes pulled up into the
 // parent) numbered in depth-first order, leaves folded into child references.
 // prim_boxes (6 floats per primitive, in BVH order) lets the flattener find subtrees whose
 // box does not contain all their primitives and mark the references to them REF_NOCULL.
+//
+// Every pass is a walk of the tree, and a tree of millions of nodes is walked as a small top part (the first nodes
+// in breadth-first order, sequentially) plus a few thousand disjoint subtrees hanging off it (in parallel): the
+// subtrees are validated, measured and boxed on their own, the top part stitches the results together, and the
+// depth-first numbering gives every subtree a contiguous run of indices that it then fills in on its own.
 static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_prims, const float* prim_boxes, FlatTree& out) {
-	uint32_t depth = 0;
-	if (!validate_tree(nodes, n_nodes, n_prims, depth)) return fail(PTX_ERR_INVALID, "node array is not a tree rooted at 0 over the given primitives");
-	out.depth = depth;
-	// Post-order pass: the box the subtree's primitives really occupy, and whether it pokes
-	// out of the node's stored box.
-	std::vector<uint8_t> sticks_out(n_nodes, 0);
+	const char* not_a_tree = "node array is not a tree rooted at 0 over the given primitives";
+	if (n_nodes == 0) return fail(PTX_ERR_INVALID, not_a_tree);
+	auto is_leaf = [&](uint32_t i) { return nodes[i].l == nodes[i].r; };
+	auto node_ok = [&](uint32_t i) {
+		const PtxBvhNode& n = nodes[i];
+		if (uint64_t(n.start) + n.size > n_prims) return false;
+		return n.l == n.r || (n.l < n_nodes && n.r < n_nodes && n.l != i && n.r != i);
+	};
+	// ---- the top part: nodes expanded in breadth-first order until enough subtrees hang off it
+	const size_t want_subtrees = n_nodes >= (1u << 17) ? size_t(build_threads()) * 128 : 0;
+	struct Top {
+		uint32_t node, depth;
+	};
+	std::vector<Top> top;            // expanded (interior) nodes, parents before children
+	std::vector<Top> roots;          // subtree roots (interior or leaf), not expanded
 	{
-		std::vector<float> real(size_t(n_nodes) * 6);
-		std::vector<uint32_t> order;   // nodes in an order where children follow parents
-		order.reserve(n_nodes);
-		std::vector<uint32_t> stack{0u};
-		while (!stack.empty()) {
-			uint32_t i = stack.back();
-			stack.pop_back();
-			order.push_back(i);
-			if (nodes[i].l != nodes[i].r) stack.push_back(nodes[i].l), stack.push_back(nodes[i].r);
-		}
-		for (size_t k = order.size(); k-- > 0;) {
-			const uint32_t i = order[k];
-			const PtxBvhNode& n = nodes[i];
-			float* b = &real[size_t(i) * 6];
-			for (int a = 0; a < 3; a++) b[a] = 3.402823466e+38f, b[3 + a] = -3.402823466e+38f;
-			auto grow = [&](const float* o) {
-				for (int a = 0; a < 3; a++) b[a] = std::min(b[a], o[a]), b[3 + a] = std::max(b[3 + a], o[3 + a]);
-			};
-			if (n.l == n.r) {
-				for (uint32_t p = n.start; p < n.start + n.size; p++) grow(prim_boxes + size_t(p) * 6);
+		std::vector<Top> queue{{0u, 0u}};
+		size_t head = 0;
+		while (head < queue.size()) {
+			const Top t = queue[head++];
+			if (!node_ok(t.node)) return fail(PTX_ERR_INVALID, not_a_tree);
+			const bool expand = !is_leaf(t.node) && (queue.size() - head) + roots.size() < want_subtrees + 1 && top.size() < size_t(n_nodes);
+			// (the first TOP_NODES interior nodes in breadth-first order must all lie in the top part)
+			if (expand || (!is_leaf(t.node) && top.size() < size_t(TOP_NODES) + 1)) {
+				top.push_back(t);
+				queue.push_back({nodes[t.node].l, t.depth + 1}), queue.push_back({nodes[t.node].r, t.depth + 1});
+				if (queue.size() > size_t(n_nodes) + 2) return fail(PTX_ERR_INVALID, not_a_tree);
 			} else {
-				grow(&real[size_t(n.l) * 6]);
-				grow(&real[size_t(n.r) * 6]);
+				roots.push_back(t);
 			}
-			bool out_of_box = false;
-			for (int a = 0; a < 3; a++) out_of_box |= (b[a] < n.bmin[a]) || (b[3 + a] > n.bmax[a]);
-			const bool holds_any = n.l != n.r || n.size > 0;
-			sticks_out[i] = (holds_any && out_of_box) ? 1 : 0;
 		}
 	}
+	// ---- per subtree: validation, depth, interior nodes, and the box its primitives really occupy per node
+	std::vector<uint8_t> sticks_out(n_nodes, 0);
+	BigVector<float> real(size_t(n_nodes) * 6);
+	auto real_box = [&](uint32_t i) {   // children (or primitives) first: called in an order where they are done
+		const PtxBvhNode& n = nodes[i];
+		float* b = &real[size_t(i) * 6];
+		for (int a = 0; a < 3; a++) b[a] = 3.402823466e+38f, b[3 + a] = -3.402823466e+38f;
+		auto grow = [&](const float* o) {
+			for (int a = 0; a < 3; a++) b[a] = std::min(b[a], o[a]), b[3 + a] = std::max(b[3 + a], o[3 + a]);
+		};
+		if (n.l == n.r) {
+			for (uint32_t p = n.start; p < n.start + n.size; p++) grow(prim_boxes + size_t(p) * 6);
+		} else {
+			grow(&real[size_t(n.l) * 6]);
+			grow(&real[size_t(n.r) * 6]);
+		}
+		bool out_of_box = false;
+		for (int a = 0; a < 3; a++) out_of_box |= (b[a] < n.bmin[a]) || (b[3 + a] > n.bmax[a]);
+		const bool holds_any = n.l != n.r || n.size > 0;
+		sticks_out[i] = (holds_any && out_of_box) ? 1 : 0;
+	};
+	struct Measure {
+		uint64_t visited = 0;
+		uint32_t interior = 0, depth = 0;
+		bool ok = true;
+	};
+	std::vector<Measure> measure(roots.size());
+	parallel_tasks(roots.size(), n_nodes, [&](size_t k) {
+		Measure m;
+		std::vector<uint32_t> order;   // the subtree's nodes, parents before children
+		std::vector<Top> stack{roots[k]};
+		while (!stack.empty() && m.ok) {
+			const Top t = stack.back();
+			stack.pop_back();
+			if (++m.visited > n_nodes || !node_ok(t.node)) {
+				m.ok = false;
+				break;
+			}
+			order.push_back(t.node);
+			m.depth = std::max(m.depth, t.depth);
+			if (is_leaf(t.node)) continue;
+			m.interior++;
+			stack.push_back({nodes[t.node].r, t.depth + 1}), stack.push_back({nodes[t.node].l, t.depth + 1});
+		}
+		if (m.ok)
+			for (size_t j = order.size(); j-- > 0;) real_box(order[j]);
+		measure[k] = m;
+	});
+	uint64_t visited = top.size();
+	uint32_t depth = 0;
+	for (const Top& t : top) depth = std::max(depth, t.depth);
+	for (const Measure& m : measure) {
+		if (!m.ok) return fail(PTX_ERR_INVALID, not_a_tree);
+		visited += m.visited;
+		depth = std::max(depth, m.depth);
+	}
+	if (visited > n_nodes) return fail(PTX_ERR_INVALID, not_a_tree);   // more visits than nodes: not a tree
+	for (size_t j = top.size(); j-- > 0;) real_box(top[j].node);        // breadth-first order reversed: children first
+	out.depth = depth;
+
 	auto leaf_ref = [&](uint32_t i, uint32_t& ref) {
 		const PtxBvhNode& n = nodes[i];
 		if (n.size > MAX_LEAF_PRIMS || n.start > MAX_LEAF_START) return false;
@@ -188,54 +284,90 @@ static int flatten_tree(const PtxBvhNode* nodes, uint32_t n_nodes, uint32_t n_pr
 	};
 	const char* too_big = "a leaf holds more than 15 primitives (or starts beyond 2^26): not representable in the GPU layout";
 	for (int k = 0; k < 3; k++) out.tame = out.tame && tame_coord_host(nodes[0].bmin[k]) && tame_coord_host(nodes[0].bmax[k]);
-	if (nodes[0].l == nodes[0].r) {
+	if (is_leaf(0)) {
 		if (!leaf_ref(0, out.root_ref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
 		return PTX_OK;
 	}
+	// ---- numbering of the interior nodes
 	std::vector<uint32_t> interior_of(n_nodes, 0xFFFFFFFFu);
 	uint32_t count = 0;
-	if (TOP_NODES > 0) {
-		// The first TOP_NODES interior nodes breadth-first: the top of the tree gets the lowest indices, which is
-		// the part k_mesh_persistent keeps in LDS (persistent.hip.h).
-		std::vector<uint32_t> queue{0u};
-		for (size_t head = 0; head < queue.size() && count < uint32_t(TOP_NODES); head++) {
-			const uint32_t i = queue[head];
-			interior_of[i] = count++;
-			const PtxBvhNode& n = nodes[i];
-			if (nodes[n.l].l != nodes[n.l].r) queue.push_back(n.l);
-			if (nodes[n.r].l != nodes[n.r].r) queue.push_back(n.r);
+	// The first TOP_NODES interior nodes breadth-first: the top of the tree gets the lowest indices, which is
+	// the part k_mesh_persistent keeps in LDS (persistent.hip.h).  `top` holds them in that very order.
+	for (size_t j = 0; j < top.size() && count < uint32_t(TOP_NODES); j++) interior_of[top[j].node] = count++;
+	// the others depth-first, left first: sequentially through the top part, a whole run of indices per subtree
+	std::vector<uint32_t> root_index(n_nodes >= (1u << 17) ? n_nodes : 0, 0xFFFFFFFFu);   // node -> position in `roots` (large trees only)
+	std::vector<uint32_t> first_index(roots.size(), 0u);
+	{
+		auto root_of = [&](uint32_t node) -> size_t {
+			if (!root_index.empty()) return root_index[node];
+			for (size_t k = 0; k < roots.size(); k++)
+				if (roots[k].node == node) return k;
+			return roots.size();
+		};
+		for (size_t k = 0; k < roots.size() && !root_index.empty(); k++) root_index[roots[k].node] = uint32_t(k);
+		std::vector<uint8_t> in_top(n_nodes, 0);
+		for (const Top& t : top) in_top[t.node] = 1;
+		std::vector<uint32_t> stack{0u};
+		while (!stack.empty()) {
+			const uint32_t i = stack.back();
+			stack.pop_back();
+			if (is_leaf(i)) continue;
+			if (in_top[i]) {
+				if (interior_of[i] == 0xFFFFFFFFu) interior_of[i] = count++;
+				stack.push_back(nodes[i].r), stack.push_back(nodes[i].l);
+			} else {
+				const size_t k = root_of(i);
+				first_index[k] = count;
+				count += measure[k].interior;
+			}
 		}
 	}
-	std::vector<uint32_t> stack{0u};
-	while (!stack.empty()) {  // number the (other) interior nodes depth-first, left first
-		uint32_t i = stack.back();
-		stack.pop_back();
-		if (interior_of[i] == 0xFFFFFFFFu) interior_of[i] = count++;
-		const PtxBvhNode& n = nodes[i];
-		if (nodes[n.r].l != nodes[n.r].r) stack.push_back(n.r);
-		if (nodes[n.l].l != nodes[n.l].r) stack.push_back(n.l);
-	}
 	if (count > REF_INDEX_MASK) return fail(PTX_ERR_UNSUPPORTED, "more than 2^30 interior nodes");
-	out.nodes.assign(count, Node2{});
-	for (uint32_t i = 0; i < n_nodes; i++) {
-		if (interior_of[i] == 0xFFFFFFFFu) continue;
-		const PtxBvhNode &n = nodes[i], &l = nodes[n.l], &r = nodes[n.r];
-		Node2& d = out.nodes[interior_of[i]];
-		// An empty leaf (the reference's "no split separates the primitives" case, bvh.cpp:183-221)
-		// carries an inverted FLT_MAX box; whether a ray "hits" it changes nothing, so store zeros.
-		const float zeros[3] = {0.0f, 0.0f, 0.0f};
-		const bool l_empty = l.l == l.r && l.size == 0, r_empty = r.l == r.r && r.size == 0;
-		d.set_box(0, l_empty ? zeros : l.bmin, l_empty ? zeros : l.bmax);
-		d.set_box(1, r_empty ? zeros : r.bmin, r_empty ? zeros : r.bmax);
-		for (int k = 0; k < 4; k++) out.tame = out.tame && tame_coord_host(d.lxy[k]) && tame_coord_host(d.z[k]) && tame_coord_host(d.rxy[k]);
-		if (l.l == l.r) {
-			if (!leaf_ref(n.l, d.lref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
-		} else d.lref = interior_of[n.l] | (sticks_out[n.l] ? REF_NOCULL : 0u);
-		if (r.l == r.r) {
-			if (!leaf_ref(n.r, d.rref)) return fail(PTX_ERR_UNSUPPORTED, too_big);
-		} else d.rref = interior_of[n.r] | (sticks_out[n.r] ? REF_NOCULL : 0u);
-		out.n_nocull += (d.lref & REF_NOCULL ? 1 : 0) + (d.rref & REF_NOCULL ? 1 : 0);
-	}
+	parallel_tasks(roots.size(), n_nodes, [&](size_t k) {
+		if (is_leaf(roots[k].node)) return;
+		uint32_t next = first_index[k];
+		std::vector<uint32_t> stack{roots[k].node};
+		while (!stack.empty()) {
+			const uint32_t i = stack.back();
+			stack.pop_back();
+			interior_of[i] = next++;
+			const PtxBvhNode& n = nodes[i];
+			if (!is_leaf(n.r)) stack.push_back(n.r);
+			if (!is_leaf(n.l)) stack.push_back(n.l);
+		}
+	});
+	// ---- the records
+	out.nodes.resize(count);
+	std::atomic<bool> tame{out.tame}, leaf_too_big{false};
+	std::atomic<uint32_t> n_nocull{0};
+	parallel_slices(n_nodes, [&](uint64_t lo, uint64_t hi) {
+		bool slice_tame = true;
+		uint32_t slice_nocull = 0;
+		for (uint64_t i = lo; i < hi; i++) {
+			if (interior_of[i] == 0xFFFFFFFFu) continue;
+			const PtxBvhNode &n = nodes[i], &l = nodes[n.l], &r = nodes[n.r];
+			Node2 d{};
+			// An empty leaf (the reference's "no split separates the primitives" case, bvh.cpp:183-221)
+			// carries an inverted FLT_MAX box; whether a ray "hits" it changes nothing, so store zeros.
+			const float zeros[3] = {0.0f, 0.0f, 0.0f};
+			const bool l_empty = l.l == l.r && l.size == 0, r_empty = r.l == r.r && r.size == 0;
+			d.set_box(0, l_empty ? zeros : l.bmin, l_empty ? zeros : l.bmax);
+			d.set_box(1, r_empty ? zeros : r.bmin, r_empty ? zeros : r.bmax);
+			for (int k = 0; k < 4; k++) slice_tame = slice_tame && tame_coord_host(d.lxy[k]) && tame_coord_host(d.z[k]) && tame_coord_host(d.rxy[k]);
+			if (l.l == l.r) {
+				if (!leaf_ref(n.l, d.lref)) leaf_too_big = true;
+			} else d.lref = interior_of[n.l] | (sticks_out[n.l] ? REF_NOCULL : 0u);
+			if (r.l == r.r) {
+				if (!leaf_ref(n.r, d.rref)) leaf_too_big = true;
+			} else d.rref = interior_of[n.r] | (sticks_out[n.r] ? REF_NOCULL : 0u);
+			slice_nocull += (d.lref & REF_NOCULL ? 1 : 0) + (d.rref & REF_NOCULL ? 1 : 0);
+			out.nodes[interior_of[i]] = d;
+		}
+		if (!slice_tame) tame = false;
+		n_nocull += slice_nocull;
+	});
+	if (leaf_too_big) return fail(PTX_ERR_UNSUPPORTED, too_big);
+	out.tame = tame, out.n_nocull = n_nocull;
 	out.root_ref = 0;
 	return PTX_OK;
 }
@@ -312,7 +444,7 @@ static void widen_tree(const FlatTree& in, std::vector<Node4>& out, uint32_t& ro
 	root_ref = 0;
 }
 
-template<typename T> static int upload(PtxScene* s, const std::vector<T>& v, const T*& dev) {
+template<typename T, typename A> static int upload(PtxScene* s, const std::vector<T, A>& v, const T*& dev) {
 	dev = nullptr;
 	if (v.empty()) return PTX_OK;
 	void* p = nullptr;
@@ -338,11 +470,11 @@ static int check_mesh_desc(const PtxMeshDesc& m) {
 }
 
 struct SceneBuild {
-	std::vector<Node2> nodes;
+	BigVector<Node2> nodes;
 	std::vector<Node4> nodes4;
 	bool want_wide = false;   // single-mesh scenes: also build the four-wide form of the tree
-	std::vector<TriGeom> tris;
-	std::vector<TriAttr> attrs;
+	BigVector<TriGeom> tris;
+	BigVector<TriAttr> attrs;
 	std::vector<MeshRec> meshes;
 	std::vector<std::vector<float>> mesh_box;  // Tri_Mesh::bbox per mesh (6 floats)
 };
@@ -399,7 +531,7 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 	laps.lap("mesh: tree");
 	if (!rec.is_list) {
 		FlatTree ft;
-		std::vector<float> ordered(boxes.size());
+		BigVector<float> ordered(boxes.size());
 		parallel_slices(m.n_tris, [&](uint64_t lo, uint64_t hi) {
 			for (uint64_t i = lo; i < hi; i++) std::copy(&boxes[size_t(bvh.order[i]) * 6], &boxes[size_t(bvh.order[i]) * 6] + 6, &ordered[size_t(i) * 6]);
 		});
@@ -409,7 +541,9 @@ static int add_mesh(PtxScene* s, SceneBuild& sb, const PtxMeshDesc& m) {
 		rec.root_ref = ft.root_ref;
 		rec.tame = ft.tame ? 1 : 0;
 		for (int k = 0; k < 3; k++) rec.root_min[k] = bvh.nodes[0].bmin[k], rec.root_max[k] = bvh.nodes[0].bmax[k];
-		sb.nodes.insert(sb.nodes.end(), ft.nodes.begin(), ft.nodes.end());
+		const bool wide = sb.want_wide;
+		if (sb.nodes.empty() && !wide) sb.nodes = std::move(ft.nodes);   // the usual case for a big mesh: no copy
+		else sb.nodes.insert(sb.nodes.end(), ft.nodes.begin(), ft.nodes.end());
 		if (sb.want_wide) {
 			std::vector<Node4> wide;
 			uint32_t skipped = 0;
@@ -464,7 +598,7 @@ static int finish_geometry(PtxScene* s, SceneBuild& sb) {
 	s->bytes_nodes = sb.nodes.size() * sizeof(Node2);
 	// k_mesh_persistent copies the first TOP_NODES records of a mesh's node array into LDS whatever the tree's size:
 	// zero records behind the last tree keep that read inside the allocation.
-	if (TOP_NODES > 0) sb.nodes.resize(sb.nodes.size() + size_t(TOP_NODES), Node2{});
+	if (TOP_NODES > 0) sb.nodes.insert(sb.nodes.end(), size_t(TOP_NODES), Node2{});
 	if (int rc = upload(s, sb.nodes, s->rec.nodes)) return rc;
 	if (int rc = upload(s, sb.nodes4, s->rec.nodes4)) return rc;
 	if (int rc = upload(s, sb.tris, s->rec.tris)) return rc;

@@ -105,8 +105,8 @@ def test_render_leg_blocks_recompute():
             assert full, name
             c = entry["kernels"][full[0]]["counters_summed_over_dispatches"]
             cycles = c["GRBM_GUI_ACTIVE"] / 8.0
-            assert k["roofs"]["valu_issue"]["frac"] == pytest.approx(4.0 * c["SQ_ACTIVE_INST_VALU"] / (cycles * CUS * 4), rel=2e-3)
-            assert k["roofs"]["valu_lanes"]["frac"] == pytest.approx(c["SQ_THREAD_CYCLES_VALU"] / (CUS * 64.0 * cycles), rel=2e-2)
+            assert k["roofs"]["valu_issue"]["frac"] == pytest.approx(4.0 * c["SQ_ACTIVE_INST_VALU"] / (cycles * CUS * 4), rel=2e-3, abs=1e-4)   # fractions are kept to four decimals
+            assert k["roofs"]["valu_lanes"]["frac"] == pytest.approx(c["SQ_THREAD_CYCLES_VALU"] / (CUS * 64.0 * cycles), rel=2e-2, abs=1e-4)
             assert all(v.get("frac", v.get("busy_frac", 0)) <= 1.0 for v in k["roofs"].values() if isinstance(v, dict))
     assert seen >= 4
 

@@ -15,3 +15,4 @@ for v in shipped "$@"; do
 	done
 	echo "[experiments] $v done"
 done
+python3 $R/tools/reduce_profiles.py $OUT

@@ -89,4 +89,5 @@ render)
 	;;
 esac
 done
+python3 $R/tools/reduce_profiles.py $OUT
 du -sh $OUT

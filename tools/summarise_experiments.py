@@ -7,7 +7,6 @@ import glob
 import json
 import os
 import re
-import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,13 +43,10 @@ def ab_times(log):
 
 
 def kernel_counters(variant, leg):
-    f = glob.glob(os.path.join(G, "prof_exp", f"{variant}_{leg}", "**", "*.db"), recursive=True)
-    if not f:
+    f = os.path.join(G, "prof_exp", f"{variant}_{leg}.json")
+    if not os.path.exists(f):
         return {}
-    c = sqlite3.connect(f[0])
-    agg = {}
-    for k, n, v in c.execute("select kernel_name, counter_name, sum(value) from counters_collection group by kernel_name, counter_name"):
-        agg.setdefault(k, {})[n] = v
+    agg = json.load(open(f)).get("counters", {})
     out = {}
     for name, label in (("k_scene_persistent<ptx::RenderIO, false, false", "extend"), ("k_shade<", "shade")):
         for k, m in agg.items():

@@ -18,7 +18,6 @@ import csv
 import glob
 import json
 import os
-import sqlite3
 import subprocess
 import sys
 
@@ -47,46 +46,43 @@ def stamp():
     return {"round": RND, "source_hash": src, "commit": commit, "csrc_modified_since_commit": dirty}
 
 
-def db(path):
-    f = glob.glob(os.path.join(G, path, "**", "*.db"), recursive=True)
-    return sqlite3.connect(f[0]) if f else None
+def reduced(path):
+    """The reduction tools/reduce_profiles.py left of one profiler pass (gpurun_out/prof/<path>.json), or None."""
+    f = os.path.join(G, path + ".json")
+    return json.load(open(f)) if os.path.exists(f) else None
 
 
 def kernel_stats(path, out_csv):
-    c = db(path)
-    if c is None:
+    r = reduced(path)
+    if not r or "kernel_stats" not in r:
         return None
-    rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
-    tot = sum(r[2] for r in rows)
+    rows = r["kernel_stats"]
+    tot = sum(x[2] for x in rows)
     with open(os.path.join(P, out_csv), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
-        for r in rows:
-            w.writerow([r[0], r[1], r[2], round(r[3], 1), round(100.0 * r[2] / tot, 3), r[4], r[5]])
+        for x in rows:
+            w.writerow([x[0], x[1], x[2], round(x[3], 1), round(100.0 * x[2] / tot, 3), x[4], x[5]])
     return rows
 
 
 def sums(path, like):
     """Per-launch mean of every counter over the dispatches of kernels whose name matches."""
-    c = db(path)
-    if c is None:
-        return {}
-    out = {}
-    for name, v, n in c.execute("select counter_name, sum(value), count(distinct dispatch_id) from counters_collection where kernel_name like ? group by counter_name", ("%" + like + "%",)):
-        out[name] = v / max(n, 1)
-    return out
+    r = reduced(path)
+    out, n = {}, 0
+    for k, m in ((r or {}).get("counters") or {}).items():
+        if like in k:
+            n += m.get("dispatches", 0)
+            for c, v in m.items():
+                if c != "dispatches":
+                    out[c] = out.get(c, 0.0) + v
+    return {c: v / max(n, 1) for c, v in out.items()}
 
 
 def totals(path):
     """Per kernel: sum of every counter over all dispatches, and the dispatch count."""
-    c = db(path)
-    agg = collections.defaultdict(dict)
-    if c is None:
-        return agg
-    for k, n, v, cnt in c.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection group by kernel_name, counter_name"):
-        agg[k][n] = v
-        agg[k]["dispatches"] = cnt
-    return agg
+    r = reduced(path)
+    return {k: dict(m) for k, m in ((r or {}).get("counters") or {}).items()}
 
 
 def derived(cnt, per_unit=None):
@@ -136,17 +132,20 @@ if kernel_stats("trace", f"{RND}_kernel_stats_bench.csv"):
         json.dump(json.loads(lines[-1]), open(os.path.join(P, f"{RND}_bench_line.json"), "w"), indent=1)
     # The command runs the culled closest-hit kernel on three meshes in turn (the 1M-triangle soup, then the two
     # 10 M-triangle meshes), seconds apart (scene construction, CPU baselines): its launches split by the gaps.
-    c = db("trace")
+    launches = reduced("trace")["traversal_launches"]
+
+    def launches_of(like):
+        return sorted((st, en) for name, rows in launches.items() if like in name for st, en in rows)
+
     by_leg = []
     legs3 = ("config 3 (1M-triangle soup)", "cows10m", "soup10m")
-    rows = c.execute("select start, end from kernels where name like ? order by start", ("%" + CLOSEST + "%",)).fetchall()
     windows = []     # a leg's window opens with its first closest-hit launch
-    for st, en in rows:
+    for st, en in launches_of(CLOSEST):
         if not windows or st - last_end > 2.0e9:
             windows.append(st)
         last_end = en
     for like, label in ((CLOSEST, "closest"), (ANYHIT, "occlusion")):
-        rows = c.execute("select start, end from kernels where name like ? order by start", ("%" + like + "%",)).fetchall()
+        rows = launches_of(like)
         for k, leg in enumerate(legs3[:len(windows)]):
             lo, hi = windows[k], windows[k + 1] if k + 1 < len(windows) else float("inf")
             d = [(en - st) / 1e6 for st, en in rows if lo <= st < hi]

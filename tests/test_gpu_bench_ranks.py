@@ -48,3 +48,26 @@ def test_two_ranks_render_the_single_rank_frame():
     # every render leg carries its rays per path and a roofline block
     for r in one["renders"]:
         assert r["roofline"]["rays_per_path"] > 1.0 and r["roofline"]["Mrays_per_s"] > 0
+
+
+def test_ranks_started_by_torch_distributed_run():
+    """The other way the bench is started: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` hands
+    it RANK / LOCAL_RANK / WORLD_SIZE itself (here with --rehearse, two ranks on the one GPU).  A short line, the same
+    checks: both ranks joined, the frames are the single-rank ones."""
+    args = ["--no-10m", "--no-4k", "--no-cpu", "--rays", "262144", "--tris", "50000", "--steps", "1", "--warmup", "1"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse"] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["collective_backend"] == "gloo"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-4000:]
+    one = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    for r1, r2 in zip(one["renders"], two["renders"]):
+        assert r1["leg"] == r2["leg"] and r1["mean_radiance"] == r2["mean_radiance"] and r1["traced_rays"] == r2["traced_rays"]
+    # a wrong --gpus is refused rather than silently run with another world size
+    bad = subprocess.run(cmd[:cmd.index("--gpus") + 1] + ["3", "--rehearse"] + args, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0

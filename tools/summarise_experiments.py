@@ -1,4 +1,4 @@
-"""Measured-and-dropped tuning experiments of one round, from the A/B timing logs (tools/ab_render.sh) and the counter
+"""Measured tuning experiments (dropped and adopted) of one round, from the A/B timing logs (tools/ab_render.sh) and the counter
 passes (tools/profile_experiments.sh):  python tools/summarise_experiments.py r03 > profiles/r03_scene_experiments.json
 Per variant: best render time per configuration against the shipped library in the same run, and for the two kernels
 that make up a render (extend: k_scene_persistent<RenderIO>, shade: k_shade) the vector-ALU busy fraction, the lanes
@@ -24,13 +24,22 @@ EXPERIMENTS = {
                 "what": "k_scene_persistent keeps the first 16 node records (breadth-first) of the instance-level tree in LDS (1 KB: what five 31 KB blocks per CU leave free)"},
     "toplds1": {"log": "ab_toplds.log", "flag": "-DPTX_SCENE_TOP_LDS=16 -DPTX_SCENE_TOP_LDS_LEVEL=1",
                 "what": "the same 1 KB holds the first 16 node records of the mesh most instances refer to (the cow)"},
+    "pathblock": {"log": "ab_pathblock.log", "flag": "-DPTX_PATH_BLOCK=1024 (against 0: sample-major)", "variant": "pb1024",
+                  "what": "which sample of which pixel a path of a pass is: 1,024 neighbouring pixels carry all the samples of the pass before the next 1,024 begin, so the few hundred "
+                          "thousand paths in flight cover a patch of the film with all its samples instead of a third of the film with one (64 and 16,384 measured the same within 0.3 %)"},
+    "xcdparts": {"log": "ab_xcdparts.log", "flag": "-DPTX_SCENE_PARTS=8 (against 1: one claim counter)", "variant": "xp8",
+                 "what": "k_scene_persistent cuts its item list into eight contiguous parts with a claim counter each; a block starts in part blockIdx % 8 (its XCD) and helps in the "
+                         "next part when its own is dry, as k_mesh_persistent does: each XCD's L2 serves neighbouring rays"},
 }
 
 
 def ab_times(log):
     """{variant: {config: best seconds}} from an ab_render.sh log."""
     out, cur = {}, None
-    for line in open(os.path.join(G, log)):
+    path = os.path.join(G, log)
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{log}")
+    for line in open(path):
         m = re.match(r"== (\S+)", line)
         if m:
             cur = m.group(1)
@@ -66,13 +75,19 @@ for name, e in EXPERIMENTS.items():
     t = ab_times(e["log"])
     entry = {"name": name, "build_flags": e["flag"], "what": e["what"], "render_seconds": {}, "bit_identical_accumulator": True, "counters_16spp": {}}
     for cfg, ship in t.get("shipped", {}).items():
-        var = t.get(name, {}).get(cfg)
+        var = t.get(e.get("variant", name), {}).get(cfg)
         if var:
             entry["render_seconds"][cfg] = {"shipped": ship["s"], "variant": var["s"], "change_percent": round(100.0 * (var["s"] / ship["s"] - 1.0), 1)}
             entry["bit_identical_accumulator"] &= var["checksum"] == ship["checksum"]
     for leg, cfg in (("refract_cow_cbox", "2"), ("instanced_cows", "5")):
-        entry["counters_16spp"][cfg] = {"shipped": kernel_counters("shipped", leg), "variant": kernel_counters(name, leg)}
+        if kernel_counters(name, leg):
+            entry["counters_16spp"][cfg] = {"shipped": kernel_counters("shipped", leg), "variant": kernel_counters(name, leg)}
     worse = [v["change_percent"] for v in entry["render_seconds"].values()]
-    entry["outcome"] = f"dropped: {min(worse):+.1f} % to {max(worse):+.1f} % render time" if worse and min(worse) > 0 else "see numbers"
+    if worse and min(worse) > 0:
+        entry["outcome"] = f"dropped: {min(worse):+.1f} % to {max(worse):+.1f} % render time"
+    elif worse and max(worse) <= 0.1:
+        entry["outcome"] = f"adopted: {min(worse):+.1f} % to {max(worse):+.1f} % render time"
+    else:
+        entry["outcome"] = "see numbers"
     result["experiments"].append(entry)
 print(json.dumps(result, indent=1))

@@ -156,6 +156,16 @@ static bool peer_readable(int reader, int owner) {
 	return state == 1;
 }
 
+// The films are read on other streams than the ones that wrote them (the destination's, or a communicator's): whatever
+// their own GPUs still have queued for them has to be finished first.
+static int wait_for_films(const ptx_frame_t* films, uint32_t n) {
+	for (uint32_t i = 0; i < n; i++) {
+		PTX_HIP(hipSetDevice(films[i]->scene->device));
+		PTX_HIP(hipStreamSynchronize(films[i]->scene->stream));
+	}
+	return PTX_OK;
+}
+
 }  // namespace ptx
 
 extern "C" int ptx_frame_reduce(ptx_frame_t dst, const ptx_frame_t* parts, uint32_t n_parts) {
@@ -166,6 +176,7 @@ extern "C" int ptx_frame_reduce(ptx_frame_t dst, const ptx_frame_t* parts, uint3
 	}
 	dst->last = PtxFrameReduceInfo{};
 	if (n_parts == 0) return PTX_OK;
+	if (int rc = wait_for_films(parts, n_parts)) return rc;
 	const int dev = dst->scene->device;
 	hipStream_t stream = dst->scene->stream;
 	PTX_HIP(hipSetDevice(dev));
@@ -392,6 +403,8 @@ extern "C" int ptx_frame_reduce_rccl(ptx_comm_t c, ptx_frame_t dst, const ptx_fr
 	if (root < 0) return fail(PTX_ERR_INVALID, "ptx_frame_reduce_rccl: the destination's GPU is not in the communicator");
 	const size_t n = dst->n_pixels;
 	const RcclApi* api = c->api;
+	if (int rc = wait_for_films(parts, n_parts)) return rc;
+	if (int rc = wait_for_films(&dst, 1)) return rc;
 	ncclResult_t r = api->GroupStart();
 	for (uint32_t i = 0; i < n_parts && r == ncclSuccess; i++) {
 		r = api->Reduce(parts[i]->accum, int(i) == root ? dst->accum : parts[i]->accum, 3 * n, ncclInt64, ncclSum, root, c->comms[i], c->streams[i]);
@@ -407,6 +420,7 @@ extern "C" int ptx_frame_allreduce(ptx_comm_t c, const ptx_frame_t* frames, uint
 	if (int rc = check_comm_frames("ptx_frame_allreduce", c, frames, n_frames)) return rc;
 	const size_t n = frames[0]->n_pixels;
 	const RcclApi* api = c->api;
+	if (int rc = wait_for_films(frames, n_frames)) return rc;
 	ncclResult_t r = api->GroupStart();
 	for (uint32_t i = 0; i < n_frames && r == ncclSuccess; i++) {
 		r = api->AllReduce(frames[i]->accum, frames[i]->accum, 3 * n, ncclInt64, ncclSum, c->comms[i], c->streams[i]);

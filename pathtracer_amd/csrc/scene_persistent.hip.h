@@ -18,8 +18,10 @@
 //          root box test or sphere test)
 //   EXIT   finished the current instance's tree: has to carry the hit back to world space
 //
-// Each loop iteration executes ONE of the four phases -- the one most lanes are ready for -- and
-// the lanes in other states wait their turn, so every phase's code runs with many lanes active.
+// Each loop iteration executes the phase most lanes are ready for, and the lanes in other states wait
+// their turn, so every phase's code runs with many lanes active.  ENTER, LEAF and EXIT are also the
+// stages a ray goes through, in this order, in a mesh whose tree is a single leaf (a quad): a stage
+// runs behind the one before it within the same iteration when that one has made enough lanes ready.
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +39,14 @@ constexpr unsigned long long SCENE_WAVE_CHUNK = 128;
 constexpr unsigned SCENE_PART_COUNTER0 = 32, SCENE_PART_COUNTER_STRIDE = 8;   // in 8-byte words of the counter block: bytes 256, 320, ... (a 64-byte line each)
 constexpr int SCENE_WALK_STEPS = 6;   // box steps per WALK phase
 constexpr int SCENE_REFILL_MIN_IDLE = 8;
+#ifndef PTX_SCENE_CHAIN_MIN
+#define PTX_SCENE_CHAIN_MIN 8
+#endif
+#ifndef PTX_SCENE_CHAIN_MIN_AFTER_LEAVES
+#define PTX_SCENE_CHAIN_MIN_AFTER_LEAVES 24
+#endif
+constexpr int SCENE_CHAIN_MIN = PTX_SCENE_CHAIN_MIN;   // lanes that make a stage worth running behind the one before it (65: never)
+constexpr int SCENE_CHAIN_MIN_AFTER_LEAVES = PTX_SCENE_CHAIN_MIN_AFTER_LEAVES;   // the same for leaving behind a triangle stage that was the iteration's own phase
 constexpr uint32_t SCENE_ITERATION_CAP = 1u << 24;   // per wave; ordinary launches stay below 2^20
 // Experiment switches (measured, see the design notes): the first PTX_SCENE_TOP_LDS node records of one tree are kept
 // in LDS -- the instance-level tree's (PTX_SCENE_TOP_LDS_LEVEL 0) or those of the mesh most instances refer to (1).
@@ -319,12 +329,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 		const int n_walk = __popcll(__ballot(can_walk)), n_tri = __popcll(__ballot(has_parked));
 		const int n_enter = __popcll(__ballot(want_enter)), n_exit = __popcll(__ballot(want_exit));
 		const int n_max = max(max(n_walk, n_tri), max(n_enter, n_exit));
+		enum { P_NONE, P_WALK, P_TRI, P_EXIT, P_ENTER };
+		const int phase = n_max == 0 ? P_NONE : n_walk == n_max ? P_WALK : n_tri == n_max ? P_TRI : n_exit == n_max ? P_EXIT : P_ENTER;
 #ifdef PTX_PROFILE_LANES
 		prof[0]++;
 #endif
-		if (n_max == 0) {
-			// nothing to execute: at most some lanes whose ray finished at once (it missed the scene's box)
-		} else if (n_walk == n_max) {
+		// (P_NONE: nothing to execute -- at most some lanes whose ray finished at once: it missed the scene's box)
+		if (phase == P_WALK) {
 			// ---- WALK: one box-test step on whichever tree the lane is in
 #ifdef PTX_PROFILE_LANES
 			prof[1]++, prof[2] += n_walk;
@@ -351,30 +362,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 					if (level == 0u) settle_top();
 				}
 			}
-		} else if (n_tri == n_max) {
-			// ---- triangle phase: every parked leaf
-#ifdef PTX_PROFILE_LANES
-			prof[3]++, prof[4] += n_tri;
-#endif
-			if (has_parked) {
-				if (MODE == MODE_CULLED) {
-					mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (pend & REF_INDEX_MASK) >> 4, pend & 15u, cr, mh, nullptr);
-					pend = 0u;
-					if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
-				} else {
-					mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (ref & REF_INDEX_MASK) >> 4, ref & 15u, cr, mh, nullptr);
-					if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
-					else pop_ref<MODE, ANY>(cr, st, base, sp, ref, mh.hit, mh.distance);
-				}
-			}
-		} else if (n_exit == n_max) {
-			// ---- leave an instance: Instance::hit's tail (instance.h:36-39): Trace::transform(T, iT.T())
-			// recomputes the distance from the transformed hit point and origin (trace.h:38-43)
-#ifdef PTX_PROFILE_LANES
-			prof[5]++, prof[6] += n_exit;
-#endif
-			if (want_exit) leave_instance();
-		} else {
+		}
+		// The other three phases are stages of one pipeline -- enter an instance, test a leaf's triangles, leave the
+		// instance -- and a mesh whose whole tree is one leaf (a wall of the Cornell box: two triangles) takes a ray
+		// through all three with no walking in between.  So a stage also runs, in the same iteration, behind the stage
+		// before it when that one has just made enough lanes ready for it (CHAIN_MIN: its instructions cost the same
+		// for one lane as for 64), and every lane that is ready for it joins, whichever stage made it ready.
+		bool chained = false;
+		if (phase == P_ENTER) {
 			// ---- enter an instance (instance.h:32-35): ray to object space, then the sphere test or the
 			// mesh's root box
 #ifdef PTX_PROFILE_LANES
@@ -428,6 +423,44 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 					}
 				}
 			}
+			// lanes that entered a mesh whose root is a leaf stand on that leaf now
+			const bool on_leaf = have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE && (MODE != MODE_CULLED || pend == 0u);
+			chained = __popcll(__ballot(on_leaf)) >= SCENE_CHAIN_MIN;
+			if (MODE == MODE_CULLED && chained) {
+				while (have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE && pend == 0u) {
+					if (ref & 15u) pend = ref;
+					pop_ref<MODE, ANY>(cr, st, base, sp, ref, mh.hit, mh.distance);
+				}
+			}
+		}
+		if (phase == P_TRI || chained) {
+			// ---- triangle stage: every parked leaf (reference order: every lane standing on a leaf of a mesh)
+			const bool at_leaf = MODE == MODE_CULLED ? (have_ray && pend != 0u) : (have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE);
+#ifdef PTX_PROFILE_LANES
+			prof[3]++, prof[4] += __popcll(__ballot(at_leaf));
+#endif
+			if (at_leaf) {
+				if (MODE == MODE_CULLED) {
+					mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (pend & REF_INDEX_MASK) >> 4, pend & 15u, cr, mh, nullptr);
+					pend = 0u;
+					if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
+				} else {
+					mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (ref & REF_INDEX_MASK) >> 4, ref & 15u, cr, mh, nullptr);
+					if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
+					else pop_ref<MODE, ANY>(cr, st, base, sp, ref, mh.hit, mh.distance);
+				}
+			}
+			const bool done_here = have_ray && level == 1u && ref == REF_DONE && pend == 0u;
+			chained = __popcll(__ballot(done_here)) >= (chained ? SCENE_CHAIN_MIN : SCENE_CHAIN_MIN_AFTER_LEAVES);
+		}
+		if (phase == P_EXIT || chained) {
+			// ---- leave an instance: Instance::hit's tail (instance.h:36-39): Trace::transform(T, iT.T())
+			// recomputes the distance from the transformed hit point and origin (trace.h:38-43)
+			const bool leaving = have_ray && level == 1u && ref == REF_DONE && pend == 0u;
+#ifdef PTX_PROFILE_LANES
+			prof[5]++, prof[6] += __popcll(__ballot(leaving));
+#endif
+			if (leaving) leave_instance();
 		}
 
 		if (have_ray && level == 0u && ref == REF_DONE) {

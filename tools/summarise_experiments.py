@@ -24,6 +24,11 @@ EXPERIMENTS = {
                 "what": "k_scene_persistent keeps the first 16 node records (breadth-first) of the instance-level tree in LDS (1 KB: what five 31 KB blocks per CU leave free)"},
     "toplds1": {"log": "ab_toplds.log", "flag": "-DPTX_SCENE_TOP_LDS=16 -DPTX_SCENE_TOP_LDS_LEVEL=1",
                 "what": "the same 1 KB holds the first 16 node records of the mesh most instances refer to (the cow)"},
+    "shadewaves6": {"log": "ab_shadewaves.log", "flag": "-DPTX_SHADE_WAVES=6", "variant": "sw6",
+                    "what": "k_shade held to the 80 registers that let six waves share a SIMD instead of four (106 registers as the compiler leaves it): 45 spilled registers"},
+    "shadewaves5": {"log": "ab_shadewaves.log", "flag": "-DPTX_SHADE_WAVES=5 -DPTX_SHADE_BLOCK=256", "variant": "sw5b256",
+                    "what": "k_shade in 256-thread blocks held to 96 registers, five waves per SIMD: 19 spilled registers (sw5 in the same log: the same with 512-thread blocks, "
+                            "whose waves come in pairs per SIMD, so four still)"},
     "pathblock": {"log": "ab_pathblock.log", "flag": "-DPTX_PATH_BLOCK=1024 (against 0: sample-major)", "variant": "pb1024",
                   "what": "which sample of which pixel a path of a pass is: 1,024 neighbouring pixels carry all the samples of the pass before the next 1,024 begin, so the few hundred "
                           "thousand paths in flight cover a patch of the film with all its samples instead of a third of the film with one (64 and 16,384 measured the same within 0.3 %)"},

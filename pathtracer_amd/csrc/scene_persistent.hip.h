@@ -39,16 +39,50 @@ constexpr unsigned long long SCENE_WAVE_CHUNK = 128;
 constexpr unsigned SCENE_PART_COUNTER0 = 32, SCENE_PART_COUNTER_STRIDE = 8;   // in 8-byte words of the counter block: bytes 256, 320, ... (a 64-byte line each)
 constexpr int SCENE_WALK_STEPS = 6;   // box steps per WALK phase
 constexpr int SCENE_REFILL_MIN_IDLE = 8;
-#ifndef PTX_SCENE_CHAIN_MIN
-#define PTX_SCENE_CHAIN_MIN 8
+// Lanes that make a stage of the loop worth running although it is not the iteration's phase (see the loop; 65: never).
+#define PTX_SCENE_THRESHOLD(NAME, VALUE) constexpr int SCENE_T_##NAME = VALUE;
+#ifndef PTX_SCENE_T_ENTER_COLD
+#define PTX_SCENE_T_ENTER_COLD 65
 #endif
-#ifndef PTX_SCENE_CHAIN_MIN_AFTER_LEAVES
-#define PTX_SCENE_CHAIN_MIN_AFTER_LEAVES 24
+#ifndef PTX_SCENE_T_WALK_COLD
+#define PTX_SCENE_T_WALK_COLD 65
 #endif
-constexpr int SCENE_CHAIN_MIN = PTX_SCENE_CHAIN_MIN;   // lanes that make a stage worth running behind the one before it (65: never)
-constexpr int SCENE_CHAIN_MIN_AFTER_LEAVES = PTX_SCENE_CHAIN_MIN_AFTER_LEAVES;   // the same for leaving behind a triangle stage that was the iteration's own phase
+#ifndef PTX_SCENE_T_ENTER_AFTER_WALK
+#define PTX_SCENE_T_ENTER_AFTER_WALK 65
+#endif
+#ifndef PTX_SCENE_T_TRI_COLD
+#define PTX_SCENE_T_TRI_COLD 65
+#endif
+#ifndef PTX_SCENE_T_TRI_AFTER_ENTER
+#define PTX_SCENE_T_TRI_AFTER_ENTER 8
+#endif
+#ifndef PTX_SCENE_T_TRI_AFTER_WALK
+#define PTX_SCENE_T_TRI_AFTER_WALK 65
+#endif
+#ifndef PTX_SCENE_T_EXIT_COLD
+#define PTX_SCENE_T_EXIT_COLD 65
+#endif
+#ifndef PTX_SCENE_T_EXIT_AFTER_TRI
+#define PTX_SCENE_T_EXIT_AFTER_TRI 8        // behind a triangle stage that itself ran behind another stage
+#endif
+#ifndef PTX_SCENE_T_EXIT_AFTER_OWN_TRI
+#define PTX_SCENE_T_EXIT_AFTER_OWN_TRI 24   // behind a triangle stage that was the iteration's phase
+#endif
+#ifndef PTX_SCENE_T_EXIT_AFTER_WALK
+#define PTX_SCENE_T_EXIT_AFTER_WALK 65
+#endif
+PTX_SCENE_THRESHOLD(ENTER_COLD, PTX_SCENE_T_ENTER_COLD)
+PTX_SCENE_THRESHOLD(WALK_COLD, PTX_SCENE_T_WALK_COLD)
+PTX_SCENE_THRESHOLD(ENTER_AFTER_WALK, PTX_SCENE_T_ENTER_AFTER_WALK)
+PTX_SCENE_THRESHOLD(TRI_COLD, PTX_SCENE_T_TRI_COLD)
+PTX_SCENE_THRESHOLD(TRI_AFTER_ENTER, PTX_SCENE_T_TRI_AFTER_ENTER)
+PTX_SCENE_THRESHOLD(TRI_AFTER_WALK, PTX_SCENE_T_TRI_AFTER_WALK)
+PTX_SCENE_THRESHOLD(EXIT_COLD, PTX_SCENE_T_EXIT_COLD)
+PTX_SCENE_THRESHOLD(EXIT_AFTER_TRI, PTX_SCENE_T_EXIT_AFTER_TRI)
+PTX_SCENE_THRESHOLD(EXIT_AFTER_OWN_TRI, PTX_SCENE_T_EXIT_AFTER_OWN_TRI)
+PTX_SCENE_THRESHOLD(EXIT_AFTER_WALK, PTX_SCENE_T_EXIT_AFTER_WALK)
 constexpr uint32_t SCENE_ITERATION_CAP = 1u << 24;   // per wave; ordinary launches stay below 2^20
-// Experiment switches (measured, see the design notes): the first PTX_SCENE_TOP_LDS node records of one tree are kept
+// Experiment switches (measured 8-14 % slower: the extra kilobyte of LDS costs a block per CU): the first PTX_SCENE_TOP_LDS node records of one tree are kept
 // in LDS -- the instance-level tree's (PTX_SCENE_TOP_LDS_LEVEL 0) or those of the mesh most instances refer to (1).
 #ifndef PTX_SCENE_TOP_LDS
 #define PTX_SCENE_TOP_LDS 0
@@ -335,47 +369,58 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 		prof[0]++;
 #endif
 		// (P_NONE: nothing to execute -- at most some lanes whose ray finished at once: it missed the scene's box)
-		if (phase == P_WALK) {
-			// ---- WALK: one box-test step on whichever tree the lane is in
+		//
+		// The four phases are the stages of a cycle a ray goes round -- walk the top-level tree, enter an instance (and
+		// walk its tree), test the leaves' triangles, leave the instance -- and the loop body runs them in this order.  The iteration's phase always runs.  Another stage runs as well when enough lanes are ready for it
+		// (its instructions cost the same for one lane as for 64): SCENE_T_<stage>_COLD lanes that were ready when the
+		// iteration began, or SCENE_T_<stage>_AFTER_<earlier stage> lanes once that earlier stage has run in this
+		// iteration and made lanes ready (65: never).  A mesh whose whole tree is one leaf -- a wall of the Cornell
+		// box: two triangles -- then takes a ray through enter, triangles and leave in one iteration.  Every lane that
+		// is ready for a stage joins it, whichever stage made it ready.
+		bool ran_enter = false, ran_walk = false, ran_tri = false;
+		{
+			const bool run = phase == P_WALK || n_walk >= SCENE_T_WALK_COLD;
+			if (run) {
+				// ---- WALK: box-test steps on whichever tree the lane is in
+				ran_walk = true;
 #ifdef PTX_PROFILE_LANES
-			prof[1]++, prof[2] += n_walk;
+				prof[1]++, prof[2] += __popcll(__ballot(have_ray && !(ref & REF_LEAF)));
 #endif
-			// Several steps in a row: choosing a phase costs about a third of a box step, and a wave that
-			// walks now mostly walks next time too.  Lanes that reach a leaf on the way sit out the rest.
-			// (Measured on two scenes: 6 steps -9 % and -17 % time against 1; parking leaves between the
-			// steps or leaving early when half the walkers are done both lose to the plain loop.)
-			for (int step = 0; step < walk_steps; step++) {
-				if (have_ray && !(ref & REF_LEAF)) {
-					const bool run_hit = level ? mh.hit : best_hit;
-					const float run_dist = level ? mh.distance : best_distance;
-					// (both orders decide with the approximate slab test, exact where it cannot tell: only the decisions matter)
-					if (STOP > 0) {
-						float4 n0, n1, n2;
-						uint2 kids;
-						const uint32_t index = ref & REF_INDEX_MASK;
-						if (cnode_base == lds_tree_base && index < uint32_t(STOP)) fetch_node_lds(lds_tree_top, index, n0, n1, n2, kids);
-						else fetch_node(sc.nodes + cnode_base + index, n0, n1, n2, kids);
-						node_decide<MODE, ANY, true, false, ZERO, true>(n0, n1, n2, kids, cr, cinv, st, base, sp, ref, run_hit, run_dist);
-					} else {
-						node_step<MODE, ANY, true, false, ZERO, true>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
+				// Several steps in a row: choosing a phase costs about a third of a box step, and a wave that
+				// walks now mostly walks next time too.  Lanes that reach a leaf on the way sit out the rest.
+				// (Measured on two scenes: 6 steps -9 % and -17 % time against 1; parking leaves between the
+				// steps or leaving early when half the walkers are done both lose to the plain loop.)
+				for (int step = 0; step < walk_steps; step++) {
+					if (have_ray && !(ref & REF_LEAF)) {
+						const bool run_hit = level ? mh.hit : best_hit;
+						const float run_dist = level ? mh.distance : best_distance;
+						// (both orders decide with the approximate slab test, exact where it cannot tell: only the decisions matter)
+						if (STOP > 0) {
+							float4 n0, n1, n2;
+							uint2 kids;
+							const uint32_t index = ref & REF_INDEX_MASK;
+							if (cnode_base == lds_tree_base && index < uint32_t(STOP)) fetch_node_lds(lds_tree_top, index, n0, n1, n2, kids);
+							else fetch_node(sc.nodes + cnode_base + index, n0, n1, n2, kids);
+							node_decide<MODE, ANY, true, false, ZERO, true>(n0, n1, n2, kids, cr, cinv, st, base, sp, ref, run_hit, run_dist);
+						} else {
+							node_step<MODE, ANY, true, false, ZERO, true>(sc.nodes + cnode_base, cr, cinv, st, base, sp, ref, run_hit, run_dist, nullptr);
+						}
+						if (level == 0u) settle_top();
 					}
-					if (level == 0u) settle_top();
 				}
 			}
 		}
-		// The other three phases are stages of one pipeline -- enter an instance, test a leaf's triangles, leave the
-		// instance -- and a mesh whose whole tree is one leaf (a wall of the Cornell box: two triangles) takes a ray
-		// through all three with no walking in between.  So a stage also runs, in the same iteration, behind the stage
-		// before it when that one has just made enough lanes ready for it (CHAIN_MIN: its instructions cost the same
-		// for one lane as for 64), and every lane that is ready for it joins, whichever stage made it ready.
-		bool chained = false;
-		if (phase == P_ENTER) {
+		bool run_enter = phase == P_ENTER || n_enter >= SCENE_T_ENTER_COLD;
+		if (!run_enter && ran_walk && SCENE_T_ENTER_AFTER_WALK <= 64)
+			run_enter = __popcll(__ballot(have_ray && level == 0u && (ref & REF_LEAF) && ref != REF_DONE)) >= SCENE_T_ENTER_AFTER_WALK;
+		if (run_enter) {
 			// ---- enter an instance (instance.h:32-35): ray to object space, then the sphere test or the
 			// mesh's root box
+			ran_enter = true;
 #ifdef PTX_PROFILE_LANES
 			prof[7]++, prof[8] += n_enter;
 #endif
-			if (want_enter) {
+			if (have_ray && level == 0u && (ref & REF_LEAF) && ref != REF_DONE) {
 				const uint32_t leaf = ref, cur_inst = (leaf & REF_INDEX_MASK) >> 4;
 				const InstRec& in = sc.insts[cur_inst];
 				Ray3 r = cr;
@@ -423,44 +468,52 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 					}
 				}
 			}
-			// lanes that entered a mesh whose root is a leaf stand on that leaf now
-			const bool on_leaf = have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE && (MODE != MODE_CULLED || pend == 0u);
-			chained = __popcll(__ballot(on_leaf)) >= SCENE_CHAIN_MIN;
-			if (MODE == MODE_CULLED && chained) {
-				while (have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE && pend == 0u) {
+		}
+		{
+			bool run = phase == P_TRI || n_tri >= SCENE_T_TRI_COLD;
+			const int need = min(ran_enter ? SCENE_T_TRI_AFTER_ENTER : 65, ran_walk ? SCENE_T_TRI_AFTER_WALK : 65);
+			if (!run && need <= 64) {
+				// lanes that have just reached a leaf park it, as at the top of the loop
+				while (MODE == MODE_CULLED && have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE && pend == 0u) {
 					if (ref & 15u) pend = ref;
 					pop_ref<MODE, ANY>(cr, st, base, sp, ref, mh.hit, mh.distance);
 				}
+				const bool ready = MODE == MODE_CULLED ? (have_ray && pend != 0u) : (have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE);
+				run = __popcll(__ballot(ready)) >= need;
 			}
-		}
-		if (phase == P_TRI || chained) {
-			// ---- triangle stage: every parked leaf (reference order: every lane standing on a leaf of a mesh)
-			const bool at_leaf = MODE == MODE_CULLED ? (have_ray && pend != 0u) : (have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE);
+			if (run) {
+				// ---- triangle stage: every parked leaf (reference order: every lane standing on a leaf of a mesh)
+				ran_tri = true;
+				const bool at_leaf = MODE == MODE_CULLED ? (have_ray && pend != 0u) : (have_ray && level == 1u && (ref & REF_LEAF) && ref != REF_DONE);
 #ifdef PTX_PROFILE_LANES
-			prof[3]++, prof[4] += __popcll(__ballot(at_leaf));
+				prof[3]++, prof[4] += __popcll(__ballot(at_leaf));
 #endif
-			if (at_leaf) {
-				if (MODE == MODE_CULLED) {
-					mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (pend & REF_INDEX_MASK) >> 4, pend & 15u, cr, mh, nullptr);
-					pend = 0u;
-					if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
-				} else {
-					mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (ref & REF_INDEX_MASK) >> 4, ref & 15u, cr, mh, nullptr);
-					if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
-					else pop_ref<MODE, ANY>(cr, st, base, sp, ref, mh.hit, mh.distance);
+				if (at_leaf) {
+					if (MODE == MODE_CULLED) {
+						mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (pend & REF_INDEX_MASK) >> 4, pend & 15u, cr, mh, nullptr);
+						pend = 0u;
+						if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
+					} else {
+						mesh_leaf<MODE, ANY, false>(sc.tris + ctri_base, (ref & REF_INDEX_MASK) >> 4, ref & 15u, cr, mh, nullptr);
+						if (ANY && mh.hit) best_hit = true, level = 0u, ref = REF_DONE, sp = 0;   // occluded: the ray is finished
+						else pop_ref<MODE, ANY>(cr, st, base, sp, ref, mh.hit, mh.distance);
+					}
 				}
 			}
-			const bool done_here = have_ray && level == 1u && ref == REF_DONE && pend == 0u;
-			chained = __popcll(__ballot(done_here)) >= (chained ? SCENE_CHAIN_MIN : SCENE_CHAIN_MIN_AFTER_LEAVES);
 		}
-		if (phase == P_EXIT || chained) {
-			// ---- leave an instance: Instance::hit's tail (instance.h:36-39): Trace::transform(T, iT.T())
-			// recomputes the distance from the transformed hit point and origin (trace.h:38-43)
-			const bool leaving = have_ray && level == 1u && ref == REF_DONE && pend == 0u;
+		{
+			bool run = phase == P_EXIT || n_exit >= SCENE_T_EXIT_COLD;
+			const int need = min(ran_tri ? (phase == P_TRI ? SCENE_T_EXIT_AFTER_OWN_TRI : SCENE_T_EXIT_AFTER_TRI) : 65, ran_walk ? SCENE_T_EXIT_AFTER_WALK : 65);
+			if (!run && need <= 64) run = __popcll(__ballot(have_ray && level == 1u && ref == REF_DONE && pend == 0u)) >= need;
+			if (run) {
+				// ---- leave an instance: Instance::hit's tail (instance.h:36-39): Trace::transform(T, iT.T())
+				// recomputes the distance from the transformed hit point and origin (trace.h:38-43)
+				const bool leaving = have_ray && level == 1u && ref == REF_DONE && pend == 0u;
 #ifdef PTX_PROFILE_LANES
-			prof[5]++, prof[6] += __popcll(__ballot(leaving));
+				prof[5]++, prof[6] += __popcll(__ballot(leaving));
 #endif
-			if (leaving) leave_instance();
+				if (leaving) leave_instance();
+			}
 		}
 
 		if (have_ray && level == 0u && ref == REF_DONE) {

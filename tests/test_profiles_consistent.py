@@ -112,7 +112,7 @@ def test_render_leg_blocks_recompute():
 
 
 def test_summaries_name_their_sources():
-    """Counter summaries of this round carry the hash of the kernel sources they were taken from, and the bench line
+    """The newest counter summaries carry the hash of the kernel sources they were taken from, and the bench line
     records for each block whether that is what was timed."""
     for stem in ("traffic", "pmc_closest", "traffic_10m", "pmc_closest_10m", "pmc_render"):
         d = json.load(open(latest(stem)))

@@ -37,6 +37,12 @@ EXPERIMENTS = {
                       "(24 for leaving behind a triangle stage that was the iteration's own phase): a ray passes a mesh whose tree is a single leaf -- a wall of the room -- in one "
                       "iteration instead of three.  In the same log: ch65 = the restructured loop with chaining off (+0.5 to +1 %: its cost in registers), ch1/ch8/ch24 = one "
                       "threshold for both, chA = never leave behind an own triangle phase, chC = 4 and 40"},
+    "stagethresholds": {"log": "ab_stages.log", "flag": "-DPTX_SCENE_T_ENTER_AFTER_WALK=24", "variant": "e24",
+                        "what": "the chained stages generalised: any stage of the loop (walk, enter, triangles, leave, in this order) may run beside the iteration's phase when a "
+                                "threshold of lanes is ready for it, at the start of the iteration (COLD) or behind an earlier stage (AFTER).  e24 = enter behind a walk stage with "
+                                "24 lanes; in the same log w24/w32/w40 = walk whenever that many lanes can, whatever the phase (+2 to +4 %), w32e24 = both.  With the stages in the "
+                                "order enter, walk, triangles, leave (profiles/r03_ab_stages_enterfirst.log) walking behind an enter stage gains 3 % on the instanced cows, but that "
+                                "order costs 18 instead of 8 spilled registers and 2-4 % on the other scenes.  Nothing beyond enter -> triangles -> leave pays"},
     "xcdparts": {"log": "ab_xcdparts.log", "flag": "-DPTX_SCENE_PARTS=8 (against 1: one claim counter)", "variant": "xp8",
                  "what": "k_scene_persistent cuts its item list into eight contiguous parts with a claim counter each; a block starts in part blockIdx % 8 (its XCD) and helps in the "
                          "next part when its own is dry, as k_mesh_persistent does: each XCD's L2 serves neighbouring rays"},
@@ -95,6 +101,8 @@ for name, e in EXPERIMENTS.items():
     worse = [v["change_percent"] for v in entry["render_seconds"].values()]
     if worse and min(worse) > 0:
         entry["outcome"] = f"dropped: {min(worse):+.1f} % to {max(worse):+.1f} % render time"
+    elif name == "stagethresholds":
+        entry["outcome"] = f"dropped: {min(worse):+.1f} % to {max(worse):+.1f} % render time (the thresholds stay in the source, set to never)"
     elif worse and (max(worse) <= 0.1 or name == "chain"):
         entry["outcome"] = f"adopted: {min(worse):+.1f} % to {max(worse):+.1f} % render time"
     else:

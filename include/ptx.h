@@ -342,8 +342,9 @@ int ptx_frame_clear(ptx_frame_t frame);
  * accumulator would hold, whatever the order (pathtracer.h:80-83).  Parts on dst's own GPU and on GPUs it can address
  * as peers (xGMI; peer access is enabled on first use) are read where they lie by one kernel per eight parts; parts it
  * cannot address are copied into staging films on dst's GPU first.  Staging memory, copy streams and events belong to
- * `dst` and are kept until it is destroyed: calls after the first allocate nothing.  No work may be in flight on the
- * parts while it runs. */
+ * `dst` and are kept until it is destroyed: calls after the first allocate nothing.  The call first waits for what the
+ * parts' own scenes have queued on their streams (a render with PTX_ASYNC still in flight); nothing new may be queued
+ * on the parts while it runs. */
 int ptx_frame_reduce(ptx_frame_t dst, const ptx_frame_t* parts, uint32_t n_parts);
 /* What the last ptx_frame_reduce into `dst` did (no counterpart in the reference: its accumulator never leaves one
  * address space). */
@@ -364,7 +365,8 @@ int ptx_frame_reduce_info(ptx_frame_t dst, PtxFrameReduceInfo* out);
  * ptx_frame_reduce_rccl: dst = sum of parts (NOT added to what dst held), parts[i] on the communicator's i-th GPU, dst
  * on one of those GPUs; dst may be one of the parts.  One ncclReduce of int64[3*W*H] and one of uint32[W*H] per rank
  * in one group.  ptx_frame_allreduce: every film ends holding the sum of all (ncclAllReduce in place) -- the exchange
- * ranks in separate processes perform through torch.distributed.  Both return when the result is complete.
+ * ranks in separate processes perform through torch.distributed.  Both first wait for the films' own streams and
+ * return when the result is complete.
  * They stand where the reference adds a tile under its mutex (pathtracer.cpp:407-427, 566-584). */
 typedef struct PtxComm* ptx_comm_t;
 int ptx_comm_create(const int* devices, uint32_t n_devices, ptx_comm_t* out);

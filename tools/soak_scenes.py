@@ -2,7 +2,8 @@
 more rays, the culled order (replenishing kernel, and one ray per lane) against the reference order on the GPU:
 hit flag, distance bits, primitive, instance, barycentrics; occlusion flags.  The first 65 536 rays of every scene are
 also compared with the CPU checker (which tools/soak_oracle_reference.py compares with the reference's own classes).
-python3 tools/soak_scenes.py [scenes] [log2_rays] > profiles/rNN_scene_soak.json"""
+The reference order itself runs twice: through the replenishing kernel's reference-order instance (what the comparisons above use)
+and one ray per lane.  python3 tools/soak_scenes.py [scenes] [log2_rays] [first_seed] > profiles/rNN_scene_soak.json"""
 import json
 import os
 import sys
@@ -23,14 +24,15 @@ def bits(a):
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+first_seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 oracle = Oracle()
 N_CHECKER = 1 << 16
 tot = {"checker_rays": 0, "closest_mismatches_vs_checker": 0, "occlusion_mismatches_vs_checker": 0, "scenes": 0, "closest_rays": 0, "occlusion_rays": 0, "closest_mismatches_persistent": 0, "closest_mismatches_plain": 0, "occlusion_mismatches_persistent": 0,
-       "occlusion_mismatches_plain": 0, "hit_fraction_sum": 0.0}
+       "occlusion_mismatches_plain": 0, "closest_mismatches_reference_plain": 0, "occlusion_mismatches_reference_plain": 0, "hit_fraction_sum": 0.0}
 bad_seeds = []
 t0 = time.time()
 for k in range(n_scenes):
-    seed = 1000 + k
+    seed = first_seed + k
     sb = random_scene(seed)
     rays = random_rays(seed, n)
     shadow = rays.copy()
@@ -52,7 +54,8 @@ for k in range(n_scenes):
     tot["occlusion_mismatches_vs_checker"] += int((ref_any[:m] != want_any).sum())
     if cbad.any() or (ref_any[:m] != want_any).any():
         bad_seeds.append({"seed": seed, "kernel": "reference order vs checker", "closest": int(cbad.sum()), "occlusion": int((ref_any[:m] != want_any).sum())})
-    for name, mode in (("persistent", abi.PTX_TRAVERSE_CULLED), ("plain", abi.PTX_TRAVERSE_CULLED | abi.PTX_NO_PERSISTENT)):
+    for name, mode in (("persistent", abi.PTX_TRAVERSE_CULLED), ("plain", abi.PTX_TRAVERSE_CULLED | abi.PTX_NO_PERSISTENT),
+                       ("reference_plain", abi.PTX_TRAVERSE_REFERENCE | abi.PTX_NO_PERSISTENT)):
         got = sc.trace_closest(rays, flags=mode)
         bad = (bits(got["hits"]["distance"]) != bits(ref["hits"]["distance"])) | (got["hits"]["prim"] != ref["hits"]["prim"])
         bad |= hit & ((got["inst"] != ref["inst"]) | (bits(got["bary"]) != bits(ref["bary"])).any(axis=1))
@@ -70,5 +73,6 @@ for k in range(n_scenes):
     if k % 10 == 9:
         print(f"[soak] {k + 1} scenes, {tot} ({time.time() - t0:.0f} s)", file=sys.stderr, flush=True)
 tot["hit_fraction_mean"] = round(tot.pop("hit_fraction_sum") / max(1, tot["scenes"]), 4)
-print(json.dumps({"what": "random two-level scenes (tests/test_gpu_fuzz.py's generator, seeds 1000..): culled order against the reference order on the GPU",
+print(json.dumps({"what": f"random two-level scenes (tests/test_gpu_fuzz.py's generator, seeds {first_seed}..): the culled order (replenishing kernel; one ray per lane) and the one-ray-per-lane reference "
+                          "order against the replenishing kernel's reference order on the GPU; the first 65 536 closest-hit and shadow rays of every scene also against the CPU checker",
                   "rays_per_scene": n, **tot, "scenes_with_differences": bad_seeds}, indent=1))

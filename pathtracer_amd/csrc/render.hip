@@ -230,6 +230,13 @@ constexpr int RAYGEN_BLOCK = 1024;
 #define PTX_SHADE_BLOCK 512
 #endif
 constexpr int SHADE_BLOCK = PTX_SHADE_BLOCK;
+#ifndef PTX_SHADE_EARLY_LOADS
+#define PTX_SHADE_EARLY_LOADS 2   // 0: every load where it is used, 1: main ray and hit early, 2: the slot record too (measured: -0.7 %, -1.1 % on config 2)
+#endif
+#ifndef PTX_SHADE_LDS_INSTS
+#define PTX_SHADE_LDS_INSTS 16
+#endif
+constexpr int SHADE_LDS_INSTS = PTX_SHADE_LDS_INSTS;   // instance records a shade block copies into LDS (scenes with at most this many; 0: never)
 // Experiment switch: waves per SIMD the compiler is asked to fit the shade kernel into (0: its own choice).
 #ifndef PTX_SHADE_WAVES
 #define PTX_SHADE_WAVES 0
@@ -343,9 +350,10 @@ struct Surface {
 	int32_t material;
 };
 
-__device__ __forceinline__ Surface rebuild_surface(const SceneRec& sc, const ShadeTables& sh, const Ray3& world, const HitRec& h) {
+// `insts`: the scene's instance table, or the block's copy of it in LDS.
+__device__ __forceinline__ Surface rebuild_surface(const InstRec* insts, const SceneRec& sc, const ShadeTables& sh, const Ray3& world, const HitRec& h) {
 	Surface s;
-	const InstRec& in = sc.insts[h.inst];
+	const InstRec& in = insts[h.inst];
 	Ray3 r = world;
 	if (in.has_transform) r = ray_transform(in.iT, world);   // Instance::hit, instance.h:33
 	V3f pos = v3(r.ox, r.oy, r.oz) + v3(r.dx, r.dy, r.dz) * h.t;   // ray.point + dir * t
@@ -399,6 +407,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK) PTX_SHADE_OCCUPANCY k_shade(Scene
                                                const uint32_t* __restrict__ count, uint32_t k0, uint32_t key0, uint32_t key1,
                                                uint32_t* __restrict__ next_list, uint32_t* __restrict__ next_count) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	// A scene of few instances (the Cornell boxes: nine) has its instance table copied into LDS by every block: each
+	// scattering vertex reads its instance's two matrices, 112 bytes per lane whichever record it is, and those
+	// reads then stay off the vector-memory return path, which is what this kernel is short of.
+	__shared__ InstRec s_insts[SHADE_LDS_INSTS > 0 ? SHADE_LDS_INSTS : 1];
+	const bool insts_in_lds = SHADE_LDS_INSTS > 0 && sc.n_insts <= uint32_t(SHADE_LDS_INSTS);
+	if (insts_in_lds) {
+		static_assert(sizeof(InstRec) % sizeof(float4) == 0, "instance records are copied in 16-byte pieces");
+		constexpr uint32_t PIECES = sizeof(InstRec) / sizeof(float4);
+		for (uint32_t k = threadIdx.x; k < sc.n_insts * PIECES; k += SHADE_BLOCK) reinterpret_cast<float4*>(s_insts)[k] = reinterpret_cast<const float4*>(sc.insts)[k];
+		__syncthreads();
+	}
 	bool alive = false, wants_direct = false;
 	uint32_t path = 0;
 	bool have_path = i < *count;
@@ -459,6 +478,19 @@ __global__ void __launch_bounds__(SHADE_BLOCK) PTX_SHADE_OCCUPANCY k_shade(Scene
 	if (have_path) {
 		SHADE_SITE(0);
 		const float4 st = rb.state[path];
+#if PTX_SHADE_EARLY_LOADS
+		// The main ray and its hit are asked for together with the state, before the direct ray's result is dealt
+		// with: nearly every listed path needs them, and the two chains of dependent loads then overlap.
+		const float4 ma = rb.ray_a[0][path], mb = rb.ray_b[0][path];
+		const float4 ha = rb.hit_a[0][path];
+		const uint2 hb = rb.hit_b[0][path];
+#endif
+#if PTX_SHADE_EARLY_LOADS >= 2
+		// likewise the slot's pixel and first sample, which seed the vertex's random numbers
+		uint32_t slot, g;
+		path_to_slot(rb, path, slot, g);
+		const SlotInfo si = load_rec(rb.slots + slot);
+#endif
 		V3f T = v3(st.x, st.y, st.z);
 		const uint32_t word = __float_as_uint(st.w);
 		uint32_t depth = path_depth(word);
@@ -477,15 +509,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK) PTX_SHADE_OCCUPANCY k_shade(Scene
 		};
 
 		// ---- the direct ray traced last round: trace(rng, new_in_ray).first (pathtracer.cpp:71-76)
-		if (word & PATH_HAS_DIRECT) {
-			SHADE_SITE(1);
-			// the direct ray itself is read back only where its direction or origin matters
-			const float4 da = rb.hit_a[1][path];
-			const uint2 db = rb.hit_b[1][path];
+		// `da`, `db`: its hit; the ray itself (`direct_ray()`) is looked at only where its direction or origin matters.
+		auto direct_first = [&](const float4 da, const uint2 db, auto direct_ray) {
 			V3f first = v3(0, 0, 0);
 			if (db.x == 0xFFFFFFFFu) {
 				if (sh.n_env_lights) {   // pathtracer.cpp:129-136
-					const float4 ra = rb.ray_a[1][path], rbb = rb.ray_b[1][path];
+					float4 ra, rbb;
+					direct_ray(ra, rbb);
 					first = env_radiance(sh, v3(ra.w, rbb.x, rbb.y));
 				}
 			} else {
@@ -498,16 +528,22 @@ __global__ void __launch_bounds__(SHADE_BLOCK) PTX_SHADE_OCCUPANCY k_shade(Scene
 						if (sh.textures[dm.tex_a].type == PTX_TEX_CONSTANT) {
 							first = tex_evaluate(sh, dm.tex_a, 0.0f, 0.0f);
 						} else {
-							const float4 ra = rb.ray_a[1][path], rbb = rb.ray_b[1][path];
+							float4 ra, rbb;
+							direct_ray(ra, rbb);
 							const Ray3 r{ra.x, ra.y, ra.z, ra.w, rbb.x, rbb.y, rbb.z, rbb.w};
 							HitRec dh{};
 							dh.distance = da.x, dh.t = da.y, dh.u = da.z, dh.v = da.w, dh.prim = db.x, dh.inst = db.y;
-							const Surface s = rebuild_surface(sc, sh, r, dh);
+							const Surface s = rebuild_surface(sc.insts, sc, sh, r, dh);
 							first = bsdf_emission(sh, dm, s.u, s.v);
 						}
 					}
 				}
 			}
+			return first;
+		};
+		if (word & PATH_HAS_DIRECT) {
+			SHADE_SITE(1);
+			const V3f first = direct_first(rb.hit_a[1][path], rb.hit_b[1][path], [&](float4& ra, float4& rbb) { ra = rb.ray_a[1][path], rbb = rb.ray_b[1][path]; });
 			const float4 wd = rb.wd[path];
 			add_radiance(first * v3(wd.x, wd.y, wd.z));
 		}
@@ -518,11 +554,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK) PTX_SHADE_OCCUPANCY k_shade(Scene
 			// sample_indirect_lighting uses `.second` only (pathtracer.cpp:118,163); it may not even have been traced
 		} else {
 			SHADE_SITE(2);
+#if !PTX_SHADE_EARLY_LOADS
 			const float4 ma = rb.ray_a[0][path], mb = rb.ray_b[0][path];
 			const float4 ha = rb.hit_a[0][path];
 			const uint2 hb = rb.hit_b[0][path];
+#endif
 			const V3f ray_o = v3(ma.x, ma.y, ma.z), ray_d = v3(ma.w, mb.x, mb.y);
-			if (hb.x == 0xFFFFFFFFu || sc.insts[hb.y].material < 0) {
+			if (hb.x == 0xFFFFFFFFu || (insts_in_lds ? s_insts[hb.y].material : sc.insts[hb.y].material) < 0) {
 				// miss: {env, {}} -- only a camera ray's (or a direct ray's) `.first` is ever used
 				if (camera && hb.x == 0xFFFFFFFFu && sh.n_env_lights) add_radiance(env_radiance(sh, ray_d));
 			} else {
@@ -530,7 +568,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) PTX_SHADE_OCCUPANCY k_shade(Scene
 				const Ray3 r{ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
 				HitRec mh{};
 				mh.distance = ha.x, mh.t = ha.y, mh.u = ha.z, mh.v = ha.w, mh.prim = hb.x, mh.inst = hb.y;
-				Surface s = rebuild_surface(sc, sh, r, mh);
+				// (two calls, not one call on a selected pointer: each then knows which memory it reads)
+				Surface s = insts_in_lds ? rebuild_surface(s_insts, sc, sh, r, mh) : rebuild_surface(sc.insts, sc, sh, r, mh);
 				const MatRec m = sh.materials[s.material];
 				if (!mat_is_sided(m.type) && dot3(s.normal, ray_d) > 0.0f) s.normal = -s.normal;   // pathtracer.cpp:143-145
 				const Frame f = frame_from_normal(s.normal);
@@ -557,9 +596,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) PTX_SHADE_OCCUPANCY k_shade(Scene
 							rb.shadow_add[item] = make_float4(add.x, add.y, add.z, 1.0f);
 						}
 					}
+#if PTX_SHADE_EARLY_LOADS < 2
 					uint32_t slot, g;
 					path_to_slot(rb, path, slot, g);
 					const SlotInfo si = load_rec(rb.slots + slot);
+#endif
 					PathRng rng;
 					rng.start(key0, key1, si.pixel, si.s_begin + k0 + g, path_draws(word));
 					// sample_direct_lighting_task4 (pathtracer.cpp:34-78): weight = attenuation [/ pdf]

@@ -29,6 +29,17 @@ EXPERIMENTS = {
     "shadewaves5": {"log": "ab_shadewaves.log", "flag": "-DPTX_SHADE_WAVES=5 -DPTX_SHADE_BLOCK=256", "variant": "sw5b256",
                     "what": "k_shade in 256-thread blocks held to 96 registers, five waves per SIMD: 19 spilled registers (sw5 in the same log: the same with 512-thread blocks, "
                             "whose waves come in pairs per SIMD, so four still)"},
+    "ldsinsts": {"log": "ab_ldsinsts.log", "flag": "-DPTX_SHADE_LDS_INSTS=16", "variant": "li16",
+                 "what": "k_shade copies the instance table of a scene with at most 16 instances into LDS (2.3 KB per block); the two matrices a scattering vertex reads -- seven 16-byte "
+                         "gathers per lane, about 40 % of the kernel's vector-memory loads -- come from LDS instead (ds_read_b128 in the ISA): -0.4 % on config 2, nothing elsewhere; "
+                         "the kernel is not held by the return path's throughput on those loads"},
+    "shadeloads": {"log": "ab_shadeloads.log", "flag": "-DPTX_SHADE_EARLY_LOADS=2 -DPTX_SHADE_LDS_INSTS=16 (against 0 and 0)", "variant": "el2li",
+                   "what": "k_shade asks for the main ray, its hit and the slot record together with the path's state, before it deals with the direct ray's result, so that the chains "
+                           "of dependent loads overlap (el1: ray and hit only, el2: the slot record too), and reads the instance records of small scenes from LDS (ldsinsts above)"},
+    "directlast": {"log": "ab_directlast.log", "flag": "(a patch, not kept: PTX_SHADE_DIRECT_LAST)", "variant": "dl",
+                   "what": "k_shade asks for the previous direct ray's hit and weight at the top and adds what it brought after the vertex's work instead of before it (only paths that "
+                           "are no camera rays have one, and their vertex adds nothing else, so the sum is the same: identical checksums): ten more live registers (106 -> 120), "
+                           "nothing gained on the area-lit scenes, +5 % on the delta-lit room"},
     "pathblock": {"log": "ab_pathblock.log", "flag": "-DPTX_PATH_BLOCK=1024 (against 0: sample-major)", "variant": "pb1024",
                   "what": "which sample of which pixel a path of a pass is: 1,024 neighbouring pixels carry all the samples of the pass before the next 1,024 begin, so the few hundred "
                           "thousand paths in flight cover a patch of the film with all its samples instead of a third of the film with one (64 and 16,384 measured the same within 0.3 %)"},
@@ -101,6 +112,10 @@ for name, e in EXPERIMENTS.items():
     worse = [v["change_percent"] for v in entry["render_seconds"].values()]
     if worse and min(worse) > 0:
         entry["outcome"] = f"dropped: {min(worse):+.1f} % to {max(worse):+.1f} % render time"
+    elif name == "directlast":
+        entry["outcome"] = f"dropped: {min(worse):+.1f} % to {max(worse):+.1f} % render time"
+    elif name == "ldsinsts":
+        entry["outcome"] = f"adopted with shadeloads: {min(worse):+.1f} % to {max(worse):+.1f} % render time on its own (within run-to-run noise)"
     elif name == "stagethresholds":
         entry["outcome"] = f"dropped: {min(worse):+.1f} % to {max(worse):+.1f} % render time (the thresholds stay in the source, set to never)"
     elif worse and (max(worse) <= 0.1 or name == "chain"):

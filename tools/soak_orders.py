@@ -1,6 +1,6 @@
 """Soak of the culled order against the reference order on bench-shaped workloads with fresh seeds (no fixture: the two
 orders against each other on the GPU; closest hit compares distance bits and primitive, occlusion the flag):
-python3 tools/soak_orders.py [rounds] [log2_rays] > profiles/rNN_order_soak.json
+python3 tools/soak_orders.py [rounds] [log2_rays] [triangle counts, comma-separated] > profiles/rNN_order_soak.json
 Odd rounds use larger triangles (more overlap along a ray, more equal-distance candidates at shared positions)."""
 import json
 import os
@@ -16,12 +16,13 @@ from pathtracer_amd import abi, capi, synth
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 n = 1 << log2n
+sizes = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (1_000_000, 300_000, 2_000_000)
 dev = torch.device("cuda", 0)
 out = {"what": "culled vs reference order on the GPU: fresh random soups and rays per round; closest hit (distance bits, primitive) and occlusion flags",
        "rays_per_round": n, "rounds": []}
 t_start = time.time()
 for k in range(rounds):
-    tris = (1_000_000, 300_000, 2_000_000)[k % 3]
+    tris = sizes[k % len(sizes)]
     half = 0.04 if k % 2 == 0 else 0.25
     verts, idx = synth.soup(tris, key=0xA000 + k, half=half)
     scene = capi.Scene.from_mesh(verts, idx, device=0)

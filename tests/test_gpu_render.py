@@ -300,3 +300,23 @@ def test_emissive_scene_same_stream(oracle):
     io, ig = images(oracle, sb, cam, capi.make_tiles(w, h, spp, 5))
     assert io.mean() > 0.01
     assert_same_stream(io, ig)
+
+
+@pytest.mark.parametrize("extra", [4, 5])
+def test_same_stream_around_the_shade_stage_instance_table_limit(oracle, extra):
+    """The shade stage reads the instance records of a scene with at most 16 instances from a copy in LDS and those of a
+    larger scene from memory: the test room with 16 and with 17 instances, each against the CPU checker driven by the
+    same random stream (Instance::hit and Trace::transform use the same two matrices either way, instance.h:32-40)."""
+    sb = scenes.instanced_scene()
+    n_before = sb.desc().n_instances
+    q = sb.add_mesh(*scenes.quad())
+    tex = sb.add_constant_texture((0.3, 0.7, 0.4))
+    mat = sb.add_material(abi.PTX_MAT_LAMBERTIAN, tex)
+    for k in range(extra):
+        sb.add_instance(q, mat, scenes.trs((-1.2 + 0.6 * k, -0.6 + 0.2 * k, 0.5), axis=(1, 0.3 * k, 0), deg=25 + 10 * k, scale=(0.25, 1, 0.2)))
+    assert sb.desc().n_instances == n_before + extra == 12 + extra
+    w, h, spp = 96, 64, 6
+    cam = camera(w, h, spp, 4)
+    io, ig = images(oracle, sb, cam, capi.make_tiles(w, h, spp, 9))
+    assert io.mean() > 0.01
+    assert_same_stream(io, ig)

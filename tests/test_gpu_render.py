@@ -320,3 +320,14 @@ def test_same_stream_around_the_shade_stage_instance_table_limit(oracle, extra):
     io, ig = images(oracle, sb, cam, capi.make_tiles(w, h, spp, 9))
     assert io.mean() > 0.01
     assert_same_stream(io, ig)
+
+
+@pytest.mark.parametrize("w,h,spp", [(30, 20, 5), (41, 25, 3), (33, 31, 7)])
+def test_same_stream_on_films_smaller_than_a_path_block(oracle, w, h, spp):
+    """Films of fewer pixels than the 1,024 slots whose samples are laid out together (600), of one block plus one
+    pixel (1,025) and just short of one (1,023): every path must still be the sample of the pixel the checker renders."""
+    sb = lit_scene("none")
+    cam = camera(w, h, spp, 3)
+    io, ig = images(oracle, sb, cam, capi.make_tiles(w, h, spp, 13))
+    assert io.mean() > 0.01
+    assert_same_stream(io, ig, rmse_rel=5e-3)

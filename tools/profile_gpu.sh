@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe, run on the GPU box through gpurun:  bash tools/profile_gpu.sh [section ...]
-# Sections: bench closest other closest10m render   (default: all; a gpurun call is limited to 20 minutes, so the
+# Sections: bench closest other closest10m render icache   (default: all but icache; a gpurun call is limited to 20 minutes, so the
 # sections are usually run in two or three calls).
 # Leaves rocprofv3 databases under gpurun_out/prof/; tools/summarise_profiles.py turns them into the summaries
 # kept under profiles/.  Counter passes are runs of their own (kernel trace and counters are never combined),
@@ -83,6 +83,13 @@ render)
 		pmc r_${leg}_l2 TCC_HIT_sum TCC_MISS_sum -- $P
 		echo "[profile] render leg $leg counters done"
 	done
+	;;
+icache)
+	# instruction-cache behaviour of the render kernels (their code is 16 KB and 46 KB)
+	for leg in refract_cow_cbox instanced_cows; do
+		pmc i_${leg} SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 $R/tools/prof_render.py 16 $leg
+	done
+	echo "[profile] instruction cache counters done"
 	;;
 *)
 	echo "unknown section $section"; exit 2

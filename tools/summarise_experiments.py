@@ -54,6 +54,10 @@ EXPERIMENTS = {
                                 "24 lanes; in the same log w24/w32/w40 = walk whenever that many lanes can, whatever the phase (+2 to +4 %), w32e24 = both.  With the stages in the "
                                 "order enter, walk, triangles, leave (profiles/r03_ab_stages_enterfirst.log) walking behind an enter stage gains 3 % on the instanced cows, but that "
                                 "order costs 18 instead of 8 spilled registers and 2-4 % on the other scenes.  Nothing beyond enter -> triangles -> leave pays"},
+    "crosscull": {"log": "ab_crosscull.log", "flag": "(a patch, not kept: PTX_SCENE_CROSS_CULL)", "variant": "cc",
+                  "what": "k_scene_persistent bounds the object-space ray of an instance it enters by the closest hit found so far in other instances (object distance t comes back as "
+                          "t * |T dir|, Trace::transform), so that subtrees and triangles beyond it are culled inside the instance as well, not only whole top-level leaves: identical "
+                          "checksums, but the top-level culling has already removed nearly all of that work, and the bound's 25 instructions per entry and 3 per box step cost more"},
     "xcdparts": {"log": "ab_xcdparts.log", "flag": "-DPTX_SCENE_PARTS=8 (against 1: one claim counter)", "variant": "xp8",
                  "what": "k_scene_persistent cuts its item list into eight contiguous parts with a claim counter each; a block starts in part blockIdx % 8 (its XCD) and helps in the "
                          "next part when its own is dry, as k_mesh_persistent does: each XCD's L2 serves neighbouring rays"},
@@ -112,7 +116,7 @@ for name, e in EXPERIMENTS.items():
     worse = [v["change_percent"] for v in entry["render_seconds"].values()]
     if worse and min(worse) > 0:
         entry["outcome"] = f"dropped: {min(worse):+.1f} % to {max(worse):+.1f} % render time"
-    elif name == "directlast":
+    elif name in ("directlast", "crosscull"):
         entry["outcome"] = f"dropped: {min(worse):+.1f} % to {max(worse):+.1f} % render time"
     elif name == "ldsinsts":
         entry["outcome"] = f"adopted with shadeloads: {min(worse):+.1f} % to {max(worse):+.1f} % render time on its own (within run-to-run noise)"
